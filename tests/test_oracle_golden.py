@@ -1,0 +1,128 @@
+"""Pin the CPU oracle against vectors produced by the imported reference (tools/make_goldens.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2s_oracle as O
+from conftest import load_npz
+
+torch.set_float32_matmul_precision("highest")
+TOL = 2e-6      # scaled units; two fp32 evaluation orders of the same aten ops
+
+
+def P(**kw):
+    base = dict(dwell_mean=12.5, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
+                min_noise=0.0, min_duration=3.0)
+    base.update(kw)
+    return O.PredictParams(**base)
+
+
+def test_chunker_matches_reference():
+    g = load_npz("chunker.npz")
+    for k in (9, 6):
+        for name, seq in zip(g["names"], g["seqs"]):
+            got = O.encode_read(str(seq), k)
+            exp = g[f"k{k}__{name}"]
+            assert got.shape == exp.shape, (k, name)
+            assert np.array_equal(got, exp), (k, name)
+
+
+def test_position_tables():
+    g = load_npz("position_enc.npz")
+    assert np.array_equal(O.sinusoid_table(16, 64).numpy(), g["enc"][0])
+    assert np.array_equal(O.sinusoid_table(250, 64).numpy(), g["dec"][0])
+
+
+def test_stages(model_case):
+    tag, sd, cfg, g = model_case
+    x = O.one_hot(g["codes"])
+    enc_out, emb_out = O.encoder(sd, cfg, x)
+    assert np.abs(emb_out.numpy() - g["emb_out"]).max() < TOL
+    assert np.abs(enc_out.numpy() - g["enc_out"]).max() < 5 * TOL
+    assert np.abs(O.noise_sampler(sd, emb_out).numpy() - g["sigma"]).max() < TOL
+    conc, rate = O.duration_params(sd, emb_out)
+    assert np.allclose(conc.numpy(), g["conc"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(rate.numpy(), g["rate"], rtol=1e-6, atol=1e-6)
+    gs = O.standard_gamma_to_sample(torch.from_numpy(g["sg"]), torch.from_numpy(g["rate"])).clamp(min=1.0)
+    assert np.array_equal(gs.numpy(), g["g"])
+
+
+def test_durations_and_lr(model_case):
+    tag, sd, cfg, g = model_case
+    B = g["codes"].shape[0]
+    dur = O.durations(P(), B, torch.from_numpy(g["g"]))
+    assert np.array_equal(dur.numpy(), g["dur_gamma"])
+    dn = O.durations(P(duration_sampling=False, dwell_std=4.0), B, None, torch.from_numpy(g["zdw"]))
+    assert np.array_equal(dn.numpy(), g["dur_normal"])
+    assert np.all(O.durations(P(duration_sampling=False), B).numpy() == 12)      # 12.5 -> 12 half-to-even
+    enc = torch.from_numpy(g["enc_out"])
+    h, sx = O.length_regulate(enc, torch.from_numpy(g["sigma"]), dur)
+    assert np.array_equal(sx.numpy(), g["sigma_ext_gamma"])
+    assert np.allclose(h.sum(-1).numpy(), g["lr_rowsum_gamma"], atol=1e-5)
+    assert (dur.sum(1) > 250).any() and (dur.sum(1) < 250).any()                # crop and pad both covered
+    y = O.decoder(sd, cfg, h)
+    assert np.abs(y.numpy() - g["y_scaled_gamma"]).max() < 10 * TOL
+
+
+CASES = [
+    ("y_gamma_nsamp", dict(), True, True, False),
+    ("y_gamma_nsamp_minnoise", dict(noise_std=1.5, min_noise=0.02), True, True, False),
+    ("y_gamma_nconst", dict(noise_sampling=False), True, True, False),
+    ("y_gamma_nonoise", dict(noise_std=0.0), True, False, False),
+    ("y_ideal", dict(noise_std=0.0, noise_sampling=False, duration_sampling=False), False, False, False),
+    ("y_ideal_nsamp", dict(duration_sampling=False), False, True, False),
+    ("y_normal_nsamp", dict(duration_sampling=False, dwell_std=4.0), False, True, True),
+    ("y_ideal_dwell31", dict(noise_std=0.0, noise_sampling=False, duration_sampling=False,
+                             dwell_mean=4000 / 130), False, False, False),
+]
+
+
+@pytest.mark.parametrize("key,over,use_g,use_z,use_zdw", CASES)
+def test_predict_step_modes(model_case, key, over, use_g, use_z, use_zdw):
+    tag, sd, cfg, g = model_case
+    out = O.predict_chunks(sd, cfg, g["codes"], P(**over),
+                           inject_g=torch.from_numpy(g["g"]) if use_g else None,
+                           inject_z01=torch.from_numpy(g["z01"]) if use_z else None,
+                           inject_zdw=torch.from_numpy(g["zdw"]) if use_zdw else None)
+    y, ref = out["signal"].numpy(), g[key]
+    assert y.shape == ref.shape
+    assert np.array_equal(y == 0, ref == 0), "zero pattern (ReLU / pad / clamp) must match exactly"
+    assert np.abs(y - ref).mean() < 1e-4 and np.abs(y - ref).max() < 2e-3      # pA
+
+
+def test_fp64_truth_distance(model_case):
+    """Report-style check: the fp32 reference sits ~1e-5 pA from an fp64 evaluation; so must the oracle."""
+    tag, sd, cfg, g = model_case
+    p = P(noise_std=0.0)
+    o32 = O.predict_chunks(sd, cfg, g["codes"], p, inject_g=torch.from_numpy(g["g"]))
+    o64 = O.predict_chunks(sd, cfg, g["codes"], p, inject_g=torch.from_numpy(g["g"]), dtype=torch.float64)
+    same = (o32["signal"] == 0) == (o64["signal"] == 0)
+    d_or = (o32["signal"].double() - o64["signal"]).abs()[same].mean().item()
+    d_ref = np.abs(g["y_gamma_nonoise"].astype(np.float64) - o64["signal"].numpy())[same.numpy()].mean()
+    assert d_or < 1e-4 and d_ref < 1e-4
+
+
+def test_export_path(model_case):
+    tag, sd, cfg, g = model_case
+    sig = load_npz(f"signals_{tag}.npz")
+    out = O.predict_chunks(sd, cfg, g["codes"], P(), inject_g=torch.from_numpy(g["g"]),
+                           inject_z01=torch.from_numpy(g["z01"]))
+    names = [str(n) for n in g["names"]]
+    order = [str(n) for n in sig["read_order"]]
+    assert order == list(dict.fromkeys(names))
+    for rid in order:
+        rows = [out["signal"][i] for i, n in enumerate(names) if n == rid]
+        got = O.strip_zeros(rows).numpy()
+        ref = sig["sig__" + rid]
+        assert got.shape == ref.shape, rid
+        assert np.abs(got - ref).max() < 2e-3
+
+
+def test_dac_conversion_profiles():
+    g = load_npz("profiles.npz")
+    for n in g["names"]:
+        n = str(n)
+        dig, sr, bps, rng, off = g[n + "__profile"][:5]
+        with np.errstate(all="ignore"):
+            raw = O.to_dac(g["signal"], dig, rng, off, rna=n.startswith("rna"))
+        assert np.array_equal(raw, g[n + "__raw"]), n
