@@ -1,0 +1,157 @@
+/* s2s_hip.h -- C ABI of the MI355X-native seq2squiggle predict path.
+ *
+ * The reference (ZKI-PH-ImageAnalysis/seq2squiggle v0.3.4) is pure Python and has no FFI of
+ * its own; this header is the boundary a maintainer binds with ctypes (INTEGRATION.md shows
+ * the stub).  Each entry point names the reference code it replaces (paths relative to the
+ * reference's src/seq2squiggle/).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is owned by the caller;
+ *   - pointers marked "device" are HIP device pointers on the handle's device;
+ *   - all launches are stream-ordered on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) and asynchronous w.r.t. the host;
+ *   - return value 0 = success, negative = error; s2s_last_error() gives the message;
+ *   - a handle may be used from one host thread at a time; there is no global state.
+ */
+#ifndef S2S_HIP_H
+#define S2S_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2S_OK 0
+#define S2S_ERR_ARG (-1)     /* bad argument / unsupported configuration */
+#define S2S_ERR_HIP (-2)     /* a HIP runtime call failed                 */
+#define S2S_ERR_BLOB (-3)    /* weight blob has the wrong size            */
+
+#define S2S_T_ENC 16         /* config.yaml:18 max_dna_len    */
+#define S2S_T_DEC 250        /* config.yaml:19 max_signal_len */
+#define S2S_DMODEL 64        /* config.yaml:25 dmodel         */
+#define S2S_DFF 256          /* config.yaml:26 dff            */
+#define S2S_HEADS 8          /* config.yaml:28,30             */
+
+/* Model hyper-parameters that change the predict arithmetic (config.yaml:17-31; the keys
+ * Encoder/Decoder.__init__ read, modules.py:22-63, 97-131).  Only the shipped architecture
+ * family is supported: dmodel 64, dff 256, 8 heads, 16 k-mers in, 250 samples out; the layer
+ * counts and the k-mer size are free. */
+typedef struct s2s_config {
+    int32_t seq_kmer;          /* 9 (dna-r10*, rna-004*) or 6 (dna-r9*), utils.py:257-260 */
+    int32_t max_dna_len;       /* must be 16  */
+    int32_t max_signal_len;    /* must be 250 */
+    int32_t dmodel;            /* must be 64  */
+    int32_t dff;               /* must be 256 */
+    int32_t n_heads;           /* must be 8 (encoder_heads == decoder_heads) */
+    int32_t encoder_layers;    /* 1..4 */
+    int32_t decoder_layers;    /* 1..4 */
+    int32_t pre_layers;        /* 0..4 */
+    float scaling_max_value;   /* 165.0, model.py:221 */
+} s2s_config;
+
+/* Per-call scalars: the attributes predict_step reads from the LightningModule
+ * (model.py:55-63, 207-240). */
+typedef struct s2s_params {
+    float dwell_mean;          /* used when duration_sampling == 0 (modules.py:420-432) */
+    float dwell_std;           /* > 0: dwell ~ N(dwell_mean, dwell_std), clamp(min_duration) */
+    float noise_std;           /* <= 0: no noise (model.py:224) */
+    float min_noise;           /* clamp of the predicted sigma (model.py:228) */
+    float min_duration;        /* clamp of the dwell (modules.py:414-416, 430-432) */
+    int32_t noise_sampling;    /* 1: per-sample sigma from the NoiseSampler (model.py:227-234) */
+    int32_t duration_sampling; /* 1: Gamma(conc, rate) dwell from the DurationSampler (modules.py:410-416) */
+    uint64_t seed;             /* key of the counter-based Philox4x32-10 generator */
+} s2s_params;
+
+/* Optional stage outputs for parity tests (all nullable, device). */
+typedef struct s2s_debug {
+    float* emb_out;            /* [B][16][64]  Encoder.forward 2nd result (modules.py:72-77) */
+    float* enc_out;            /* [B][16][64]  Encoder.forward 1st result (modules.py:80-89) */
+    float* sigma;              /* [B][16]      NoiseSampler.forward (modules.py:275-278) */
+    float* conc;               /* [B][16]      DurationSampler conc, clamped (modules.py:215-216) */
+    float* rate;               /* [B][16]      DurationSampler rate, clamped (modules.py:217-218) */
+    float* g;                  /* [B][16]      the dwell value before round() (modules.py:414-416/420-432) */
+    float* y_scaled;           /* [B][250]     Decoder.forward output (modules.py:140-141) */
+    float* z01;                /* [B][250]     the standard normals used for the noise term */
+} s2s_debug;
+
+typedef struct s2s_handle s2s_handle;
+
+/* Number of fp32 values the weight blob must hold for `cfg`, and the order:
+ *   encoders.position_enc[16*64]; src_emb.weight[64][5k], .bias[64];
+ *   pre_net_stack.i.weight[64][64], .bias[64]                               (i < pre_layers)
+ *   per encoder layer: LAYER (below)
+ *   noise_sampler.stdv_layer: 0.weight[64][64], 0.bias[64], 3.weight[64], 3.bias[1]
+ *   duration_sampler.conc_layer: same four; duration_sampler.rate_layer: same four
+ *   decoders.position_enc[250*64]; per decoder layer: LAYER;
+ *   decoders.out_linear.weight[64], .bias[1]
+ * LAYER = slf_attn.{w_qs,w_ks,w_vs}.{weight[64][64],bias[64]}, slf_attn.fc.{weight,bias},
+ *         slf_attn.layer_norm.{weight,bias}[64], pos_ffn.w_1.{weight[256][64],bias[256]},
+ *         pos_ffn.w_2.{weight[64][256],bias[64]}, pos_ffn.layer_norm.{weight,bias}[64]
+ * i.e. the reference state_dict (SURVEY.md section 8 a-W) in its native [out][in] layouts. */
+size_t s2s_blob_floats(const s2s_config* cfg);
+
+/* Replaces seq2squiggle.load_from_checkpoint + .to(device) (inference.py:386-399): takes the
+ * host fp32 blob, re-packs it into MFMA fragment order and uploads it to `device`. */
+int s2s_create(const s2s_config* cfg, const void* weights_blob, size_t blob_bytes, int device,
+               s2s_handle** out);
+void s2s_destroy(s2s_handle* h);
+
+/* Last error of this handle (or of the last failed s2s_create when h == NULL, thread-local). */
+const char* s2s_last_error(const s2s_handle* h);
+
+/* Replaces seq2squiggle.predict_step up to the clamp (model.py:195-240) for B chunks.
+ *
+ *  bases    device [B][16+k-1] ASCII: chunk c of a read is read[16c : 16c+15+k]
+ *           (split_sequence, utils.py:350-356); bytes past the read's end are ignored;
+ *  n_valid  device [B], 1..16: k-mers j >= n_valid are the all-"_" pad k-mer
+ *           (add_remainder, utils.py:342-347), not a shifted window;
+ *  first_global_chunk  index of chunk 0 in the whole job: the RNG counter is
+ *           (first_global_chunk + b, position, draw kind), so results do not depend on batch
+ *           size or on how chunks are sharded over GPUs;
+ *  inject_g   nullable device [B][16]: value of Gamma.sample() (modules.py:221-222) to use
+ *             instead of the built-in sampler (duration_sampling only);
+ *  inject_zdw nullable device [B][16]: standard normals for the dwell_std > 0 mode;
+ *  inject_z01 nullable device [B][250]: standard normals for the noise term;
+ *  out_signal device [B][250] fp32 pA (rows of `prediction`, model.py:240);
+ *  out_dur    device [B][16] int32 rounded dwell (modules.py:437-438);
+ *  dbg        nullable.
+ */
+int s2s_predict_chunks(s2s_handle* h, void* stream, const uint8_t* bases, const uint8_t* n_valid,
+                       int64_t first_global_chunk, int32_t B, const s2s_params* params,
+                       const float* inject_g, const float* inject_zdw, const float* inject_z01,
+                       float* out_signal, int32_t* out_dur, const s2s_debug* dbg);
+
+/* Replaces the per-read cat + zero-strip of export_and_clear_results (model.py:284-286) and the
+ * pA -> int16 conversion of BLOW5Writer/POD5Writer.save (signal_io.py:134-141, 246-253).
+ *
+ *  signal       device [B][250] (output of s2s_predict_chunks), chunks of a read contiguous;
+ *  read_first   device [R+1]: read r owns chunks read_first[r] .. read_first[r+1]-1;
+ *  out_offsets  device [R+1] int64: on return out_offsets[r] is the start of read r in the
+ *               packed output, out_offsets[R] the total sample count;
+ *  out_pa       nullable device fp32 [capacity]: packed non-zero samples (the tensors handed to
+ *               writer.signals, model.py:290);
+ *  out_dac      nullable device int16 [capacity]: round_half_even(pa*digitisation/range - offset)
+ *               wrapped to int16; reversed per read when rna != 0 (signal_io.py:140-141);
+ *  capacity     size of out_pa/out_dac in samples (B*250 always suffices).
+ */
+int s2s_export_reads(s2s_handle* h, void* stream, const float* signal, int32_t B,
+                     const int32_t* read_first, int32_t R, int64_t* out_offsets, float* out_pa,
+                     int16_t* out_dac, int64_t capacity, float digitisation, float range,
+                     float offset_mean, int32_t rna);
+
+/* Test hook: raw Philox4x32-10 words, out[i*4..i*4+3] = philox(counter = {c0+i, c1, c2, c3}, key = seed). */
+int s2s_philox_u32(s2s_handle* h, void* stream, uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
+                   uint32_t c3, int32_t n, uint32_t* out /* device [n][4] */);
+
+/* Average device time (ms) of the dominant (decoder) kernel over the launches since the last
+ * call, measured with HIP events on the launch stream when profiling is enabled. */
+int s2s_set_profiling(s2s_handle* h, int32_t enabled);
+int s2s_get_kernel_ms(s2s_handle* h, double* decoder_ms_total, int64_t* decoder_launches,
+                      int64_t* decoder_chunks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2S_HIP_H */

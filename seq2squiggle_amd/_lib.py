@@ -1,0 +1,60 @@
+"""ctypes binding of include/s2s_hip.h.  Fails loudly when the HIP library is missing."""
+import ctypes as C
+import os
+
+from ._build import LIB
+
+_lib = None
+
+
+class S2SConfig(C.Structure):
+    _fields_ = [("seq_kmer", C.c_int32), ("max_dna_len", C.c_int32), ("max_signal_len", C.c_int32),
+                ("dmodel", C.c_int32), ("dff", C.c_int32), ("n_heads", C.c_int32), ("encoder_layers", C.c_int32),
+                ("decoder_layers", C.c_int32), ("pre_layers", C.c_int32), ("scaling_max_value", C.c_float)]
+
+
+class S2SParams(C.Structure):
+    _fields_ = [("dwell_mean", C.c_float), ("dwell_std", C.c_float), ("noise_std", C.c_float),
+                ("min_noise", C.c_float), ("min_duration", C.c_float), ("noise_sampling", C.c_int32),
+                ("duration_sampling", C.c_int32), ("seed", C.c_uint64)]
+
+
+class S2SDebug(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("emb_out", "enc_out", "sigma", "conc", "rate", "g", "y_scaled", "z01")]
+
+
+EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks",
+           "s2s_export_reads", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms")
+
+
+def lib():
+    """The loaded libs2s_hip.so (built by `python -m seq2squiggle_amd._build` / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise RuntimeError(f"HIP extension not built: {LIB} is missing (run __graft_entry__.build()); "
+                           "there is no CPU fallback for the predict path")
+    L = C.CDLL(LIB)
+    vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+    L.s2s_blob_floats.restype = C.c_size_t
+    L.s2s_blob_floats.argtypes = [C.POINTER(S2SConfig)]
+    L.s2s_create.restype = i32
+    L.s2s_create.argtypes = [C.POINTER(S2SConfig), vp, C.c_size_t, i32, C.POINTER(vp)]
+    L.s2s_destroy.restype = None
+    L.s2s_destroy.argtypes = [vp]
+    L.s2s_last_error.restype = C.c_char_p
+    L.s2s_last_error.argtypes = [vp]
+    L.s2s_predict_chunks.restype = i32
+    L.s2s_predict_chunks.argtypes = [vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp, vp, vp, vp,
+                                     C.POINTER(S2SDebug)]
+    L.s2s_export_reads.restype = i32
+    L.s2s_export_reads.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i64, f32, f32, f32, i32]
+    L.s2s_philox_u32.restype = i32
+    L.s2s_philox_u32.argtypes = [vp, vp, u64, u32, u32, u32, u32, i32, vp]
+    L.s2s_set_profiling.restype = i32
+    L.s2s_set_profiling.argtypes = [vp, i32]
+    L.s2s_get_kernel_ms.restype = i32
+    L.s2s_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
+    _lib = L
+    return L

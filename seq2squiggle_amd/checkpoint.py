@@ -1,0 +1,65 @@
+"""Checkpoint reading: the Lightning .ckpt the reference trains and loads.
+
+Reference: seq2squiggle.load_from_checkpoint (inference.py:386-397) reads
+ckpt["hyper_parameters"] and ckpt["state_dict"]; ModelCheckpoint(save_weights_only=True)
+(train.py:81-87) writes them.  Here the file is read with plain torch.load and flattened
+into the fp32 blob of include/s2s_hip.h (s2s_blob_floats documents the order).
+"""
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import S2SConfig
+
+_LAYER = ("slf_attn.w_qs.weight", "slf_attn.w_qs.bias", "slf_attn.w_ks.weight", "slf_attn.w_ks.bias",
+          "slf_attn.w_vs.weight", "slf_attn.w_vs.bias", "slf_attn.fc.weight", "slf_attn.fc.bias",
+          "slf_attn.layer_norm.weight", "slf_attn.layer_norm.bias", "pos_ffn.w_1.weight", "pos_ffn.w_1.bias",
+          "pos_ffn.w_2.weight", "pos_ffn.w_2.bias", "pos_ffn.layer_norm.weight", "pos_ffn.layer_norm.bias")
+_MLP = ("0.weight", "0.bias", "3.weight", "3.bias")
+
+
+def load_checkpoint(path: str) -> Tuple[Dict[str, torch.Tensor], dict]:
+    """-> (state_dict, config).  Only `state_dict` and `hyper_parameters["config"]` are required."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    if "state_dict" not in ck:
+        raise ValueError(f"{path}: not a seq2squiggle checkpoint (no 'state_dict')")
+    cfg = (ck.get("hyper_parameters") or {}).get("config")
+    if cfg is None:
+        raise ValueError(f"{path}: checkpoint carries no hyper_parameters['config']")
+    return {k: v.detach().float().cpu() for k, v in ck["state_dict"].items()}, dict(cfg)
+
+
+def blob_names(cfg: dict):
+    names = ["encoders.position_enc", "encoders.src_emb.weight", "encoders.src_emb.bias"]
+    for i in range(cfg["pre_layers"]):
+        names += [f"encoders.pre_net_stack.{i}.weight", f"encoders.pre_net_stack.{i}.bias"]
+    for l in range(cfg["encoder_layers"]):
+        names += [f"encoders.layer_stack.{l}.{n}" for n in _LAYER]
+    for head in ("noise_sampler.stdv_layer", "length_regulator.duration_sampler.conc_layer",
+                 "length_regulator.duration_sampler.rate_layer"):
+        names += [f"{head}.{n}" for n in _MLP]
+    names.append("decoders.position_enc")
+    for l in range(cfg["decoder_layers"]):
+        names += [f"decoders.layer_stack_FFT.{l}.{n}" for n in _LAYER]
+    names += ["decoders.out_linear.weight", "decoders.out_linear.bias"]
+    return names
+
+
+def state_dict_to_blob(sd: Dict[str, torch.Tensor], cfg: dict) -> np.ndarray:
+    missing = [n for n in blob_names(cfg) if n not in sd]
+    if missing:
+        raise ValueError(f"state_dict lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
+    return np.concatenate([sd[n].detach().float().cpu().numpy().ravel() for n in blob_names(cfg)]).astype(np.float32)
+
+
+def config_to_c(cfg: dict) -> S2SConfig:
+    if cfg["encoder_heads"] != cfg["decoder_heads"]:
+        raise ValueError("encoder_heads != decoder_heads is not supported")
+    if cfg.get("allowed_chars", "_ACGT") != "_ACGT":
+        raise ValueError("allowed_chars must be '_ACGT'")
+    return S2SConfig(seq_kmer=int(cfg["seq_kmer"]), max_dna_len=int(cfg["max_dna_len"]),
+                     max_signal_len=int(cfg["max_signal_len"]), dmodel=int(cfg["dmodel"]), dff=int(cfg["dff"]),
+                     n_heads=int(cfg["encoder_heads"]), encoder_layers=int(cfg["encoder_layers"]),
+                     decoder_layers=int(cfg["decoder_layers"]), pre_layers=int(cfg["pre_layers"]),
+                     scaling_max_value=float(cfg["scaling_max_value"]))

@@ -1,0 +1,329 @@
+// s2s_device.h -- device-side building blocks of the predict path (gfx950 / CDNA4 only).
+//
+// Everything runs "transposed": an activation tile lives in registers as X^T[feature][time]
+// in the C/D layout of v_mfma_f32_16x16x4_f32 (lane = (g = lane>>4, c = lane&15); register r of
+// feature-tile ft holds feature 16*ft + 4*g + r of time column c).  In that layout an
+// accumulator is directly the B operand of the next MFMA (k-step (ft, r) supplies k-index
+// 16*ft + 4*g + r), so a whole FFT block runs register-to-register; weights are the A operand,
+// pre-packed on the host into fragment order ([m-tile][k-tile][lane][4], 1 KiB per
+// wave-load).  Only K and V cross waves, through LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define S2S_MAX_LAYERS 4
+
+struct LayerOff {
+    int wq, wk, wv, wfc, w1, w2;            // packed A fragments (float offsets into the arena)
+    int bq, bk, bv, bfc, b1, b2;            // biases (bq/bk in the q/k row permutation)
+    int ln1g, ln1b, ln2g, ln2b;
+};
+struct MlpOff { int w0, b0, w3, b3; };
+struct ModelDev {
+    int k, enc_layers, dec_layers, pre_layers;
+    float scale;                            // scaling_max_value
+    int pe_enc, pe_dec;                     // [T][64] natural
+    int emb_wt, emb_b;                      // W_emb^T [5k][64], bias [64]
+    int pre_w[S2S_MAX_LAYERS], pre_b[S2S_MAX_LAYERS];
+    LayerOff enc[S2S_MAX_LAYERS], dec[S2S_MAX_LAYERS];
+    MlpOff noise, conc, rate;
+    int out_w, out_b;
+};
+struct ParamsDev {
+    float dwell_mean, dwell_std, noise_std, min_noise, min_duration;
+    int noise_sampling, duration_sampling;
+    unsigned seed_lo, seed_hi;
+};
+struct DebugDev {
+    float *emb_out, *enc_out, *sigma, *conc, *rate, *g, *y_scaled, *z01;
+};
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float sum_g(float v) { v += xor16(v); v += xor32(v); return v; }   // over the 4 lane groups
+__device__ __forceinline__ float max_g(float v) { v = fmaxf(v, xor16(v)); v = fmaxf(v, xor32(v)); return v; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: the draw for (chunk, position, kind) never
+// depends on batch size, launch geometry or GPU count.
+struct u32x4 { unsigned x, y, z, w; };
+__device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                               unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01_open0(unsigned x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; }  // (0,1]
+__device__ __forceinline__ float u01_open1(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }        // [0,1)
+__device__ __forceinline__ float box_muller(unsigned a, unsigned b) {
+    return sqrtf(-2.0f * logf(u01_open0(a))) * cosf(6.283185307179586f * u01_open1(b));
+}
+enum { S2S_KIND_GAMMA = 1, S2S_KIND_DWELL = 2, S2S_KIND_NOISE = 3 };
+
+// torch._standard_gamma (ATen/native/Distributions.h sample_gamma: Marsaglia-Tsang 2000 with the
+// alpha < 1 boost), drawn from Philox; `iter` bounds the rejection loop (acceptance > 95 %).
+__device__ float standard_gamma(float alpha, unsigned chunk_lo, unsigned chunk_hi, unsigned pos,
+                                unsigned k0, unsigned k1) {
+    float scale = 1.0f;
+    unsigned draw = 0;
+    if (alpha < 1.0f) {
+        if (alpha == 0.0f) return 0.0f;
+        const u32x4 r = philox4x32_10(chunk_lo, chunk_hi, pos | (S2S_KIND_GAMMA << 16), draw++, k0, k1);
+        scale *= powf(1.0f - u01_open1(r.x), 1.0f / alpha);
+        alpha += 1.0f;
+    }
+    const float d = alpha - 1.0f / 3.0f;
+    const float c = 1.0f / sqrtf(9.0f * d);
+    float v = 1.0f;
+    for (int iter = 0; iter < 256; ++iter) {
+        const u32x4 r = philox4x32_10(chunk_lo, chunk_hi, pos | (S2S_KIND_GAMMA << 16), draw++, k0, k1);
+        const float x = box_muller(r.x, r.y);
+        const float y = 1.0f + c * x;
+        if (y <= 0.0f) continue;
+        v = y * y * y;
+        const float u = 1.0f - u01_open1(r.z);
+        const float xx = x * x;
+        if (u < 1.0f - 0.0331f * xx * xx) break;
+        if (logf(u) < 0.5f * xx + d * (1.0f - v + logf(v))) break;
+    }
+    return scale * d * v;
+}
+
+__device__ __forceinline__ float softplus_t(float x) {      // nn.Softplus(beta=1, threshold=20)
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS geometry of one attention block: K as float2 planes [head][d-pair g][key], V^T rows
+// [pair][16 rows][key], a zero strip for the masked half of the PV A-operand.
+template <int NKT> struct AttnLds {
+    static constexpr int KEYS = 16 * NKT;
+    static constexpr int KPS = ((KEYS % 32) == 16) ? KEYS : KEYS + 16;   // float2 per plane, == 16 mod 32
+    static constexpr int RS = KEYS + 4;                                  // floats per V row, == 4 mod 8
+    static constexpr int K_FLOATS = 8 * 4 * KPS * 2;
+    static constexpr int V_FLOATS = 4 * 16 * RS;
+    static constexpr int Z_FLOATS = KEYS;
+    static constexpr int FLOATS = K_FLOATS + V_FLOATS + Z_FLOATS;
+    static constexpr int BYTES = FLOATS * 4;
+};
+
+// acc[q][mt] (+)= W[mt-th 16 rows] * X[q]  for MT m-tiles; W packed [mt][KT][64][4].
+template <int NQ, int MT, int KT>
+__device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int lane, f32x4 (&acc)[NQ][MT],
+                                         const f32x4 (&x)[NQ][KT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const f32x4 a = ldg4(wp + ((mt * KT + kt) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMA4(a[r], x[q][kt][r], acc[q][mt]);
+            }
+        }
+    }
+}
+
+// nn.LayerNorm(64, eps=1e-5) over the feature axis (registers + the 4 lane groups), in place.
+template <int NQ>
+__device__ __forceinline__ void layer_norm64(f32x4 (&x)[NQ][4], const float* __restrict__ gam,
+                                             const float* __restrict__ bet, int g) {
+    f32x4 gm[4], bt[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) { gm[ft] = ldg4(gam + 16 * ft + 4 * g); bt[ft] = ldg4(bet + 16 * ft + 4 * g); }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float s = 0.0f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += x[q][ft][r];
+        const float mean = sum_g(s) * (1.0f / 64.0f);
+        float v = 0.0f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = x[q][ft][r] - mean; v += d * d; }
+        const float rstd = 1.0f / sqrtf(sum_g(v) * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[q][ft][r] = (x[q][ft][r] - mean) * rstd * gm[ft][r] + bt[ft][r];
+    }
+}
+
+// One FFTBlock (layers.py:116-142): post-LN multi-head attention (layers.py:44-88, 11-41; no
+// mask in predict, model.py:217) + position-wise FFN (layers.py:91-113), eval mode.
+//   X    : this wave's NQ time tiles of the block input, replaced by the block output;
+//   qt0  : index of the wave's first time tile inside the workgroup's sequence;
+//   NKT  : key tiles of the whole sequence (all waves of the workgroup together);
+//   TV   : number of real keys (keys >= TV are phantom padding and get probability 0).
+template <int NQ, int NKT, int TV>
+__device__ __forceinline__ void fft_block(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
+                                          float* __restrict__ lds, int qt0, int lane) {
+    using G = AttnLds<NKT>;
+    const int g = lane >> 4, c = lane & 15;
+    f32x2* __restrict__ Kl = reinterpret_cast<f32x2*>(lds);
+    float* __restrict__ Vl = lds + G::K_FLOATS;
+    const float* __restrict__ Zl = Vl + G::V_FLOATS;
+
+    __syncthreads();                       // every wave is done reading the previous block's K/V
+    // ---- K^T and V^T of this wave's time tiles, all heads -> LDS (layers.py:74-78)
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        f32x4 ak[NQ][1], av[NQ][1];
+        const f32x4 bk = ldg4(W + L.bk + 16 * p + 4 * g), bv = ldg4(W + L.bv + 16 * p + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { ak[q][0] = bk; av[q][0] = bv; }
+        gemm_acc<NQ, 1, 4>(W + L.wk + p * 4 * 256, lane, ak, X);
+        gemm_acc<NQ, 1, 4>(W + L.wv + p * 4 * 256, lane, av, X);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int key = 16 * (qt0 + q) + c;
+            // rows of the packed Wk tile are permuted so that registers {0,1} are head 2p
+            // (d = 2g, 2g+1) and registers {2,3} head 2p+1: exactly the float2 the S MFMA reads
+            Kl[((2 * p + 0) * 4 + g) * G::KPS + key] = f32x2{ak[q][0][0], ak[q][0][1]};
+            Kl[((2 * p + 1) * 4 + g) * G::KPS + key] = f32x2{ak[q][0][2], ak[q][0][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vl[(p * 16 + 4 * g + r) * G::RS + key] = av[q][0][r];
+        }
+    }
+    if (qt0 == 0 && lane < G::Z_FLOATS / 4)      // zero strip (<= 64 float4)
+        reinterpret_cast<f32x4*>(lds + G::K_FLOATS + G::V_FLOATS)[lane] = f32x4{0, 0, 0, 0};
+
+    // ---- fc accumulator starts as bias + residual (layers.py:85-86)
+    f32x4 acc[NQ][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = ldg4(W + L.bfc + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
+    }
+    __syncthreads();                       // K/V of every wave visible
+
+    const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        // Q^T of head pair p for this wave's time tiles (same row permutation as K)
+        f32x4 qp[NQ][1];
+        {
+            const f32x4 bq = ldg4(W + L.bq + 16 * p + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) qp[q][0] = bq;
+            gemm_acc<NQ, 1, 4>(W + L.wq + p * 4 * 256, lane, qp, X);
+        }
+        f32x4 op[NQ];                      // O^T of the pair: rows 0-7 head 2p, rows 8-15 head 2p+1
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) op[q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x2* kp = Kl + ((2 * p + hh) * 4 + g) * G::KPS + c;
+            const float* vp = ((c >> 3) == hh) ? (Vl + (p * 16 + c) * G::RS + 4 * g) : (Zl + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 s[NKT];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const f32x2 a = kp[16 * kt];
+                    s[kt] = MFMA4(a[0], qp[q][0][2 * hh], (f32x4{0, 0, 0, 0}));
+                    s[kt] = MFMA4(a[1], qp[q][0][2 * hh + 1], s[kt]);
+                }
+                if (TV < 16 * NKT) {       // phantom keys -> -inf (only the last key tile has any)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * (NKT - 1) + 4 * g + r >= TV) s[NKT - 1][r] = -__builtin_inff();
+                }
+                float m = s[0][0];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+                m = max_g(m);
+                const float mc = -m * c1;
+                float l = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, mc));
+                        s[kt][r] = e;
+                        l += e;
+                    }
+                l = sum_g(l);
+                f32x4 o0 = f32x4{0, 0, 0, 0}, o1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 16 * kt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (kt & 1) o1 = MFMA4(a[r], s[kt][r], o1);
+                        else        o0 = MFMA4(a[r], s[kt][r], o0);
+                    }
+                }
+                const float inv = 1.0f / l;
+                op[q] += (o0 + o1) * inv;  // the other head's rows are exact zeros
+            }
+        }
+        // fc: acc += Wfc[:, 16p : 16p+16] * O_pair^T
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 a = ldg4(W + L.wfc + ((mt * 4 + p) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMA4(a[r], op[q][r], acc[q][mt]);
+        }
+    }
+    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+
+    // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;      // X = bias + residual accumulator
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < 4; ++hc) {
+        f32x4 hid[NQ][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hid[q][mt] = b;
+        }
+        gemm_acc<NQ, 4, 4>(W + L.w1 + hc * 16 * 256, lane, hid, acc);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(hid[q][mt][r], 0.0f);
+        // W2 packed [4 mt][16 kt]: this slice uses k-tiles 4hc .. 4hc+3
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 a = ldg4(W + L.w2 + ((mt * 16 + 4 * hc + kt) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) X[q][mt] = MFMA4(a[r], hid[q][kt][r], X[q][mt]);
+            }
+        }
+    }
+    layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+}

@@ -1,0 +1,656 @@
+// s2s_hip.hip -- kernels and C ABI (include/s2s_hip.h) of the MI355X-native seq2squiggle
+// predict path.  gfx950 only; no fallbacks.
+//
+// Two launches per tile of chunks:
+//   s2s_frontend_kernel  one wave per chunk: k-mer embedding gather, pre-net, encoder FFT blocks,
+//                        noise / duration heads, Philox Gamma or Normal dwell -> enc_out, sigma, dur
+//   s2s_decoder_kernel   one 8-wave workgroup per chunk: length-regulator gather + positional
+//                        add, decoder FFT blocks (T = 250 padded to 256; 32 time columns per
+//                        wave), output projection, x165, Philox noise, clamp -> signal[250]
+// plus s2s_export_* for the per-read zero-strip / int16 conversion.
+#include "s2s_device.h"
+#include "../../include/s2s_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ================================================================================ frontend
+template <int MT>
+__device__ __forceinline__ void relu_tiles(f32x4 (&x)[1][MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[0][mt][r] = fmaxf(x[0][mt][r], 0.0f);
+}
+
+// Linear(64,64)+ReLU+Linear(64,1)+Softplus on emb_out (modules.py:267-278, 182-195).
+__device__ __forceinline__ float mlp_head(const float* __restrict__ W, const MlpOff m, const f32x4 (&s)[1][4],
+                                          int lane) {
+    const int g = lane >> 4;
+    f32x4 hid[1][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) hid[0][mt] = ldg4(W + m.b0 + 16 * mt + 4 * g);
+    gemm_acc<1, 4, 4>(W + m.w0, lane, hid, s);
+    relu_tiles<4>(hid);
+    float part = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 w = ldg4(W + m.w3 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += hid[0][mt][r] * w[r];
+    }
+    return softplus_t(sum_g(part) + W[m.b3]);
+}
+
+__device__ __forceinline__ int base_code(unsigned char ch) {       // utils.py:74 letter_to_int
+    return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'T' ? 4 : ch == '_' ? 0 : -1;
+}
+
+__global__ __launch_bounds__(64) void s2s_frontend_kernel(
+    const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
+    const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
+    const float* __restrict__ inj_g, const float* __restrict__ inj_zdw, float* __restrict__ ws_enc,
+    float* __restrict__ ws_sigma, int* __restrict__ out_dur, DebugDev dbg, long long dbg_base) {
+    __shared__ __attribute__((aligned(16))) float lds[AttnLds<1>::FLOATS];
+    const int b = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int k = M.k, nb = S2S_T_ENC + k - 1;
+    const uint8_t* bp = bases + (size_t)b * nb;
+    const int nv = n_valid[b];
+
+    // ---- src_emb on the one-hot k-mer == bias + sum of k gathered columns of W_emb (modules.py:70-73)
+    f32x4 X[1][4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) X[0][ft] = ldg4(W + M.emb_b + 16 * ft + 4 * g);
+    for (int j = 0; j < k; ++j) {
+        const int code = (c < nv) ? base_code(bp[c + j]) : 0;       // pad k-mer = "_" * k (utils.py:342-347)
+        const float* row = W + M.emb_wt + (5 * j + (code < 0 ? 0 : code)) * 64 + 4 * g;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const f32x4 w = ldg4(row + 16 * ft);
+            if (code >= 0) X[0][ft] += w;                            // unknown letter: all-zero one-hot row (utils.py:86)
+        }
+    }
+    relu_tiles<4>(X);
+#pragma unroll 1
+    for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
+        f32x4 Y[1][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) Y[0][mt] = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
+        gemm_acc<1, 4, 4>(W + M.pre_w[i], lane, Y, X);
+        relu_tiles<4>(Y);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) X[0][mt] = Y[0][mt];
+    }
+    f32x4 S[1][4];                                                   // emb_out
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        S[0][ft] = X[0][ft];
+        X[0][ft] += ldg4(W + M.pe_enc + c * 64 + 16 * ft + 4 * g);  // modules.py:80
+    }
+    if (dbg.emb_out) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+            *reinterpret_cast<f32x4*>(dbg.emb_out + ((dbg_base + b) * 16 + c) * 64 + 16 * ft + 4 * g) = S[0][ft];
+    }
+#pragma unroll 1
+    for (int l = 0; l < M.enc_layers; ++l) fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+        *reinterpret_cast<f32x4*>(ws_enc + ((size_t)b * 16 + c) * 64 + 16 * ft + 4 * g) = X[0][ft];
+    if (dbg.enc_out) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+            *reinterpret_cast<f32x4*>(dbg.enc_out + ((dbg_base + b) * 16 + c) * 64 + 16 * ft + 4 * g) = X[0][ft];
+    }
+
+    // ---- NoiseSampler (modules.py:275-278)
+    const float sigma = mlp_head(W, M.noise, S, lane);
+    if (g == 0) {
+        ws_sigma[b * 16 + c] = sigma;
+        if (dbg.sigma) dbg.sigma[(dbg_base + b) * 16 + c] = sigma;
+    }
+    // ---- dwell source (modules.py:396-438)
+    float gv;
+    if (P.duration_sampling) {
+        const float conc = fmaxf(mlp_head(W, M.conc, S, lane), 1e-8f);      // modules.py:215-216
+        const float rate = fmaxf(mlp_head(W, M.rate, S, lane), 1e-8f);      // modules.py:217-218
+        if (g == 0) {
+            if (dbg.conc) dbg.conc[(dbg_base + b) * 16 + c] = conc;
+            if (dbg.rate) dbg.rate[(dbg_base + b) * 16 + c] = rate;
+        }
+        if (inj_g) {
+            gv = inj_g[b * 16 + c];
+        } else {
+            const unsigned long long chunk = (unsigned long long)(first_chunk + b);
+            float sg = 0.0f;
+            if (g == 0) sg = standard_gamma(conc, (unsigned)chunk, (unsigned)(chunk >> 32), c, P.seed_lo, P.seed_hi);
+            gv = fmaxf(sg / rate, 1.17549435e-38f);                 // Gamma.sample: /rate, clamp_(tiny)
+        }
+        gv = fmaxf(gv, 1.0f);                                       // modules.py:223
+        gv = fmaxf(gv, P.min_duration);                             // modules.py:414-416
+    } else if (P.dwell_std <= 0.0f) {
+        gv = P.dwell_mean;                                          // modules.py:420-423
+    } else {
+        float z;
+        if (inj_zdw) {
+            z = inj_zdw[b * 16 + c];
+        } else {
+            const unsigned long long chunk = (unsigned long long)(first_chunk + b);
+            const u32x4 r = philox4x32_10((unsigned)chunk, (unsigned)(chunk >> 32), c | (S2S_KIND_DWELL << 16), 0,
+                                          P.seed_lo, P.seed_hi);
+            z = box_muller(r.x, r.y);
+        }
+        gv = fmaxf(__fadd_rn(P.dwell_mean, __fmul_rn(z, P.dwell_std)), P.min_duration);   // modules.py:425-432
+    }
+    if (g == 0) {
+        const float rd = fminf(fmaxf(rintf(gv), -1.0e9f), 1.0e9f);  // torch.round: half-to-even (modules.py:437)
+        out_dur[b * 16 + c] = (int)rd;
+        if (dbg.g) dbg.g[(dbg_base + b) * 16 + c] = gv;
+    }
+}
+
+// ================================================================================ decoder
+#define DEC_WAVES 8
+#define DEC_NQ 2            // 16-column time tiles per wave: 8 waves x 2 x 16 = 256 >= 250
+#define DEC_NKT 16
+
+__global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
+    const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
+    const float* __restrict__ ws_sigma, const int* __restrict__ dur, long long first_chunk, ParamsDev P,
+    const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int qt0 = DEC_NQ * wave;
+
+    // ---- length regulator (modules.py:344-392) as a gather: row t copies encoder row
+    //      i(t) = #{j : cum[j] <= t}; rows past cum[15] are zero; crop at 250; then + position_enc
+    //      (modules.py:136, also on the zero rows)
+    int cum[16];
+    {
+        int run = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { run += dur[b * 16 + j]; cum[j] = run; }
+    }
+    f32x4 X[DEC_NQ][4];
+    float sig_ext[DEC_NQ];
+#pragma unroll
+    for (int q = 0; q < DEC_NQ; ++q) {
+        const int t = 16 * (qt0 + q) + c;
+        int idx = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) idx += (cum[j] <= t) ? 1 : 0;
+        const bool live = idx < 16, real = t < S2S_T_DEC;
+        const float* er = ws_enc + ((size_t)b * 16 + (live ? idx : 0)) * 64 + 4 * g;
+        const float* pr = W + M.pe_dec + (real ? t : 0) * 64 + 4 * g;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const f32x4 e = ldg4(er + 16 * ft), pe = ldg4(pr + 16 * ft);
+            X[q][ft] = real ? ((live ? e : f32x4{0, 0, 0, 0}) + pe) : f32x4{0, 0, 0, 0};
+        }
+        sig_ext[q] = live ? ws_sigma[b * 16 + (live ? idx : 0)] : 0.0f;
+    }
+#pragma unroll 1
+    for (int l = 0; l < M.dec_layers; ++l) fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane);
+
+    // ---- out_linear + ReLU (modules.py:140-141), x165 (model.py:221), noise where != 0
+    //      (model.py:224-238), clamp (model.py:240)
+    f32x4 wo[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) wo[ft] = ldg4(W + M.out_w + 16 * ft + 4 * g);
+    const float bo = W[M.out_b];
+#pragma unroll
+    for (int q = 0; q < DEC_NQ; ++q) {
+        const int t = 16 * (qt0 + q) + c;
+        float part = 0.0f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += X[q][ft][r] * wo[ft][r];
+        const float ys = fmaxf(sum_g(part) + bo, 0.0f);
+        float y = __fmul_rn(ys, M.scale);
+        if (g == 0 && t < S2S_T_DEC) {
+            if (dbg.y_scaled) dbg.y_scaled[(dbg_base + b) * S2S_T_DEC + t] = ys;
+            if (P.noise_std > 0.0f) {
+                float z;
+                if (inj_z01) {
+                    z = inj_z01[(size_t)b * S2S_T_DEC + t];
+                } else {
+                    const unsigned long long chunk = (unsigned long long)(first_chunk + b);
+                    const u32x4 r = philox4x32_10((unsigned)chunk, (unsigned)(chunk >> 32),
+                                                  (unsigned)t | (S2S_KIND_NOISE << 16), 0, P.seed_lo, P.seed_hi);
+                    z = box_muller(r.x, r.y);
+                }
+                if (dbg.z01) dbg.z01[(dbg_base + b) * S2S_T_DEC + t] = z;
+                const float sd = P.noise_sampling
+                                     ? __fmul_rn(__fmul_rn(fmaxf(sig_ext[q], P.min_noise), P.noise_std), M.scale)
+                                     : P.noise_std;
+                if (y != 0.0f) y = __fadd_rn(y, __fmul_rn(z, sd));
+            }
+            out_signal[(size_t)b * S2S_T_DEC + t] = fmaxf(y, 0.0f);
+        }
+    }
+}
+
+// ================================================================================ export
+// per-chunk count of non-zero samples (model.py:286 strips by value)
+__global__ __launch_bounds__(256) void s2s_count_kernel(const float* __restrict__ signal, int B, int* __restrict__ counts) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    int n = 0;
+    for (int t = lane; t < S2S_T_DEC; t += 64) n += signal[(size_t)b * S2S_T_DEC + t] != 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) counts[b] = n;
+}
+
+// exclusive scan of counts[B] -> offs[B+1] (int64), one workgroup walking the array
+__global__ __launch_bounds__(1024) void s2s_scan_kernel(const int* __restrict__ counts, int B, long long* __restrict__ offs) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int i = base + tid;
+        long long v = (i < B) ? counts[i] : 0, x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        long long pre = carry_s;
+        for (int j = 0; j < w; ++j) pre += wsum[j];
+        if (i < B) offs[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) offs[B] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void s2s_read_offsets_kernel(const long long* __restrict__ offs, const int* __restrict__ read_first,
+                                                               int R, long long* __restrict__ out_offsets) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r <= R) out_offsets[r] = offs[read_first[r]];
+}
+
+__global__ __launch_bounds__(256) void s2s_compact_kernel(const float* __restrict__ signal, int B, const long long* __restrict__ offs,
+                                                          const int* __restrict__ read_first, int R, float* __restrict__ out_pa,
+                                                          short* __restrict__ out_dac, long long capacity, float dig, float range,
+                                                          float offset, int rna) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    long long pos = offs[b];
+    long long r_lo = 0, r_hi = 0;
+    if (rna && out_dac) {                      // read that owns chunk b: last r with read_first[r] <= b
+        int lo = 0, hi = R;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (read_first[mid] <= b) lo = mid; else hi = mid; }
+        r_lo = offs[read_first[lo]];
+        r_hi = offs[read_first[lo + 1]];
+    }
+    for (int t0 = 0; t0 < S2S_T_DEC; t0 += 64) {
+        const int t = t0 + lane;
+        const float v = (t < S2S_T_DEC) ? signal[(size_t)b * S2S_T_DEC + t] : 0.0f;
+        const bool keep = v != 0.0f;
+        const unsigned long long mask = __ballot(keep);
+        const long long dst = pos + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep && dst < capacity) {
+            if (out_pa) out_pa[dst] = v;
+            if (out_dac) {
+                // signal_io.py:135-138: float32 ops, no contraction; round half-to-even; int16 wrap
+                const float raw = rintf(__fsub_rn(__fdiv_rn(__fmul_rn(v, dig), range), offset));
+                const short s = (short)(int)fminf(fmaxf(raw, -2147483648.0f), 2147483520.0f);
+                out_dac[rna ? (r_lo + (r_hi - 1 - dst)) : dst] = s;
+            }
+        }
+        pos += __popcll(mask);
+    }
+}
+
+__global__ void s2s_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                  int n, unsigned* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 r = philox4x32_10(c0 + (unsigned)i, c1, c2, c3, seed_lo, seed_hi);
+    out[4 * i + 0] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+// ================================================================================ host side
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; int chunks; };
+
+}  // namespace
+
+struct s2s_handle {
+    s2s_config cfg;
+    int device = 0;
+    ModelDev model;
+    float* d_arena = nullptr;
+    size_t arena_floats = 0;
+    int tile = 0;                     // chunks per launch pair
+    float* ws_enc = nullptr;          // [tile][16][64]
+    float* ws_sigma = nullptr;        // [tile][16]
+    int* ws_counts = nullptr;         // export scratch, grown on demand outside of launches
+    long long* ws_offs = nullptr;
+    int ws_export_cap = 0;
+    bool profiling = false;
+    std::vector<EventPair> events;
+    std::string err;
+};
+
+namespace {
+
+int fail(s2s_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((h), S2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+size_t layer_floats() { return 4 * (64 * 64 + 64) + 2 * 64 + (256 * 64 + 256) + (64 * 256 + 64) + 2 * 64; }
+size_t mlp_floats() { return 64 * 64 + 64 + 64 + 1; }
+
+const char* check_cfg(const s2s_config* c) {
+    if (!c) return "config is NULL";
+    if (c->seq_kmer < 1 || c->seq_kmer > 16) return "seq_kmer must be 1..16";
+    if (c->max_dna_len != S2S_T_ENC) return "max_dna_len must be 16";
+    if (c->max_signal_len != S2S_T_DEC) return "max_signal_len must be 250";
+    if (c->dmodel != S2S_DMODEL) return "dmodel must be 64";
+    if (c->dff != S2S_DFF) return "dff must be 256";
+    if (c->n_heads != S2S_HEADS) return "n_heads must be 8";
+    if (c->encoder_layers < 1 || c->encoder_layers > S2S_MAX_LAYERS) return "encoder_layers must be 1..4";
+    if (c->decoder_layers < 1 || c->decoder_layers > S2S_MAX_LAYERS) return "decoder_layers must be 1..4";
+    if (c->pre_layers < 0 || c->pre_layers > S2S_MAX_LAYERS) return "pre_layers must be 0..4";
+    return nullptr;
+}
+
+// Arena builder: every piece starts on a 16-byte boundary (float4 loads).
+struct Arena {
+    std::vector<float> v;
+    int put(const float* p, size_t n) {
+        while (v.size() % 4) v.push_back(0.0f);
+        const int off = (int)v.size();
+        v.insert(v.end(), p, p + n);
+        return off;
+    }
+    // W [M][K] row-major -> A fragments [M/16][K/16][64 lanes][4]; lane (g, i): W[perm(16mt+i)][16kt+4g+r]
+    int put_afrag(const float* W, int M, int K, bool qk_perm) {
+        std::vector<float> t((size_t)M * K);
+        for (int mt = 0; mt < M / 16; ++mt)
+            for (int kt = 0; kt < K / 16; ++kt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, i = lane & 15;
+                    const int row = 16 * mt + (qk_perm ? perm16(i) : i);
+                    for (int r = 0; r < 4; ++r)
+                        t[(((size_t)mt * (K / 16) + kt) * 64 + lane) * 4 + r] = W[(size_t)row * K + 16 * kt + 4 * g + r];
+                }
+        return put(t.data(), t.size());
+    }
+    int put_bias_perm(const float* b, int M) {
+        std::vector<float> t(M);
+        for (int i = 0; i < M; ++i) t[i] = b[16 * (i / 16) + perm16(i % 16)];
+        return put(t.data(), t.size());
+    }
+    // packed row i = 4g'+r' of a q/k tile takes natural row 8*(r'>>1) + 2g' + (r'&1): after the MFMA,
+    // accumulator registers {0,1} hold head 0 (d = 2g, 2g+1) and {2,3} head 1 of the pair.
+    static int perm16(int i) { return 8 * ((i & 3) >> 1) + 2 * (i >> 2) + (i & 1); }
+};
+
+const float* take(const float*& p, size_t n) { const float* q = p; p += n; return q; }
+
+LayerOff pack_layer(Arena& A, const float*& p) {
+    LayerOff L;
+    const float* wq = take(p, 4096); const float* bq = take(p, 64);
+    const float* wk = take(p, 4096); const float* bk = take(p, 64);
+    const float* wv = take(p, 4096); const float* bv = take(p, 64);
+    const float* wfc = take(p, 4096); const float* bfc = take(p, 64);
+    const float* ln1g = take(p, 64); const float* ln1b = take(p, 64);
+    const float* w1 = take(p, 256 * 64); const float* b1 = take(p, 256);
+    const float* w2 = take(p, 64 * 256); const float* b2 = take(p, 64);
+    const float* ln2g = take(p, 64); const float* ln2b = take(p, 64);
+    L.wq = A.put_afrag(wq, 64, 64, true);   L.bq = A.put_bias_perm(bq, 64);
+    L.wk = A.put_afrag(wk, 64, 64, true);   L.bk = A.put_bias_perm(bk, 64);
+    L.wv = A.put_afrag(wv, 64, 64, false);  L.bv = A.put(bv, 64);
+    L.wfc = A.put_afrag(wfc, 64, 64, false); L.bfc = A.put(bfc, 64);
+    L.w1 = A.put_afrag(w1, 256, 64, false); L.b1 = A.put(b1, 256);
+    L.w2 = A.put_afrag(w2, 64, 256, false); L.b2 = A.put(b2, 64);
+    L.ln1g = A.put(ln1g, 64); L.ln1b = A.put(ln1b, 64);
+    L.ln2g = A.put(ln2g, 64); L.ln2b = A.put(ln2b, 64);
+    return L;
+}
+
+MlpOff pack_mlp(Arena& A, const float*& p) {
+    MlpOff m;
+    const float* w0 = take(p, 4096); const float* b0 = take(p, 64);
+    const float* w3 = take(p, 64);   const float* b3 = take(p, 1);
+    m.w0 = A.put_afrag(w0, 64, 64, false); m.b0 = A.put(b0, 64);
+    m.w3 = A.put(w3, 64); m.b3 = A.put(b3, 1);
+    return m;
+}
+
+ParamsDev to_dev(const s2s_params* p) {
+    ParamsDev d;
+    d.dwell_mean = p->dwell_mean; d.dwell_std = p->dwell_std; d.noise_std = p->noise_std;
+    d.min_noise = p->min_noise; d.min_duration = p->min_duration;
+    d.noise_sampling = p->noise_sampling; d.duration_sampling = p->duration_sampling;
+    d.seed_lo = (unsigned)p->seed; d.seed_hi = (unsigned)(p->seed >> 32);
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t s2s_blob_floats(const s2s_config* c) {
+    if (check_cfg(c)) return 0;
+    return (size_t)16 * 64 + (size_t)64 * 5 * c->seq_kmer + 64 + (size_t)c->pre_layers * (4096 + 64) +
+           (size_t)(c->encoder_layers + c->decoder_layers) * layer_floats() + 3 * mlp_floats() + (size_t)250 * 64 + 64 + 1;
+}
+
+int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int device, s2s_handle** out) {
+    if (!out) return fail(nullptr, S2S_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (const char* m = check_cfg(cfg)) return fail(nullptr, S2S_ERR_ARG, m);
+    if (!blob) return fail(nullptr, S2S_ERR_ARG, "weights_blob is NULL");
+    if (blob_bytes != s2s_blob_floats(cfg) * sizeof(float)) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "weight blob is %zu bytes, expected %zu", blob_bytes, s2s_blob_floats(cfg) * sizeof(float));
+        return fail(nullptr, S2S_ERR_BLOB, buf);
+    }
+    int ndev = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(nullptr, S2S_ERR_ARG, "no such HIP device");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, S2S_ERR_ARG, std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only");
+
+    s2s_handle* h = new s2s_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    const int k = cfg->seq_kmer;
+    Arena A;
+    ModelDev& M = h->model;
+    std::memset(&M, 0, sizeof M);
+    M.k = k; M.enc_layers = cfg->encoder_layers; M.dec_layers = cfg->decoder_layers; M.pre_layers = cfg->pre_layers;
+    M.scale = cfg->scaling_max_value;
+    const float* p = static_cast<const float*>(blob);
+    M.pe_enc = A.put(take(p, 16 * 64), 16 * 64);
+    {   // src_emb.weight [64][5k] -> transposed [5k][64] so a one-hot column is one contiguous row
+        const float* w = take(p, (size_t)64 * 5 * k);
+        std::vector<float> wt((size_t)5 * k * 64);
+        for (int f = 0; f < 64; ++f)
+            for (int i = 0; i < 5 * k; ++i) wt[(size_t)i * 64 + f] = w[(size_t)f * 5 * k + i];
+        M.emb_wt = A.put(wt.data(), wt.size());
+        M.emb_b = A.put(take(p, 64), 64);
+    }
+    for (int i = 0; i < cfg->pre_layers; ++i) {
+        const float* w = take(p, 4096);
+        M.pre_w[i] = A.put_afrag(w, 64, 64, false);
+        M.pre_b[i] = A.put(take(p, 64), 64);
+    }
+    for (int l = 0; l < cfg->encoder_layers; ++l) M.enc[l] = pack_layer(A, p);
+    M.noise = pack_mlp(A, p);
+    M.conc = pack_mlp(A, p);
+    M.rate = pack_mlp(A, p);
+    M.pe_dec = A.put(take(p, 250 * 64), 250 * 64);
+    for (int l = 0; l < cfg->decoder_layers; ++l) M.dec[l] = pack_layer(A, p);
+    M.out_w = A.put(take(p, 64), 64);
+    M.out_b = A.put(take(p, 1), 1);
+    while (A.v.size() % 4) A.v.push_back(0.0f);
+    h->arena_floats = A.v.size();
+
+    auto bail = [&](hipError_t e, const char* what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        s2s_destroy(h);
+        return S2S_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&h->d_arena, h->arena_floats * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(arena)");
+    if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(arena)");
+    h->tile = 32768;
+    if ((e = hipMalloc(&h->ws_enc, (size_t)h->tile * 16 * 64 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(ws_enc)");
+    if ((e = hipMalloc(&h->ws_sigma, (size_t)h->tile * 16 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(ws_sigma)");
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 AttnLds<DEC_NKT>::BYTES)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute(decoder LDS)");
+    *out = h;
+    return S2S_OK;
+}
+
+void s2s_destroy(s2s_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (auto& ev : h->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (h->d_arena) (void)hipFree(h->d_arena);
+    if (h->ws_enc) (void)hipFree(h->ws_enc);
+    if (h->ws_sigma) (void)hipFree(h->ws_sigma);
+    if (h->ws_counts) (void)hipFree(h->ws_counts);
+    if (h->ws_offs) (void)hipFree(h->ws_offs);
+    delete h;
+}
+
+const char* s2s_last_error(const s2s_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const uint8_t* n_valid, int64_t first_global_chunk,
+                       int32_t B, const s2s_params* params, const float* inject_g, const float* inject_zdw,
+                       const float* inject_z01, float* out_signal, int32_t* out_dur, const s2s_debug* dbg) {
+    if (!h) return S2S_ERR_ARG;
+    if (B < 0) return fail(h, S2S_ERR_ARG, "B < 0");
+    if (B == 0) return S2S_OK;
+    if (!bases || !n_valid || !params || !out_signal || !out_dur) return fail(h, S2S_ERR_ARG, "NULL argument");
+    if (!(params->min_duration >= 0.0f)) return fail(h, S2S_ERR_ARG, "min_duration must be >= 0");
+    if (!params->duration_sampling && !(params->dwell_std > 0.0f) && !(params->dwell_mean >= 0.0f))
+        return fail(h, S2S_ERR_ARG, "dwell_mean must be >= 0");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const ParamsDev P = to_dev(params);
+    DebugDev D;
+    std::memset(&D, 0, sizeof D);
+    if (dbg) {
+        D.emb_out = dbg->emb_out; D.enc_out = dbg->enc_out; D.sigma = dbg->sigma; D.conc = dbg->conc;
+        D.rate = dbg->rate; D.g = dbg->g; D.y_scaled = dbg->y_scaled; D.z01 = dbg->z01;
+    }
+    const int nb = S2S_T_ENC + h->cfg.seq_kmer - 1;
+    for (int64_t s = 0; s < B; s += h->tile) {
+        const int n = (int)((B - s < h->tile) ? (B - s) : h->tile);
+        hipLaunchKernelGGL(s2s_frontend_kernel, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, bases + (size_t)s * nb,
+                           n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
+                           inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
+        EventPair ev{};
+        if (h->profiling) {
+            HIP_TRY(h, hipEventCreate(&ev.a));
+            HIP_TRY(h, hipEventCreate(&ev.b));
+            HIP_TRY(h, hipEventRecord(ev.a, stream));
+        }
+        hipLaunchKernelGGL(s2s_decoder_kernel, dim3(n), dim3(DEC_WAVES * 64), AttnLds<DEC_NKT>::BYTES, stream, h->model,
+                           h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, (long long)(first_global_chunk + s), P,
+                           inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
+                           (long long)s);
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(ev.b, stream));
+            ev.chunks = n;
+            h->events.push_back(ev);
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return S2S_OK;
+}
+
+int s2s_export_reads(s2s_handle* h, void* stream_, const float* signal, int32_t B, const int32_t* read_first, int32_t R,
+                     int64_t* out_offsets, float* out_pa, int16_t* out_dac, int64_t capacity, float digitisation,
+                     float range, float offset_mean, int32_t rna) {
+    if (!h) return S2S_ERR_ARG;
+    if (B < 0 || R < 0) return fail(h, S2S_ERR_ARG, "negative size");
+    if (!signal || !read_first || !out_offsets) return fail(h, S2S_ERR_ARG, "NULL argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (B + 1 > h->ws_export_cap) {          // grows outside of the steady state only
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        if (h->ws_counts) (void)hipFree(h->ws_counts);
+        if (h->ws_offs) (void)hipFree(h->ws_offs);
+        h->ws_counts = nullptr; h->ws_offs = nullptr; h->ws_export_cap = 0;
+        const int cap = B + 1 + B / 4;
+        HIP_TRY(h, hipMalloc(&h->ws_counts, (size_t)cap * sizeof(int)));
+        HIP_TRY(h, hipMalloc(&h->ws_offs, (size_t)cap * sizeof(long long)));
+        h->ws_export_cap = cap;
+    }
+    if (B > 0) hipLaunchKernelGGL(s2s_count_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, signal, B, h->ws_counts);
+    hipLaunchKernelGGL(s2s_scan_kernel, dim3(1), dim3(1024), 0, stream, h->ws_counts, B, h->ws_offs);
+    hipLaunchKernelGGL(s2s_read_offsets_kernel, dim3((R + 256) / 256), dim3(256), 0, stream, h->ws_offs, read_first, R,
+                       reinterpret_cast<long long*>(out_offsets));
+    if (B > 0 && (out_pa || out_dac))
+        hipLaunchKernelGGL(s2s_compact_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, signal, B, h->ws_offs, read_first, R,
+                           out_pa, reinterpret_cast<short*>(out_dac), (long long)capacity, digitisation, range, offset_mean,
+                           rna);
+    HIP_TRY(h, hipGetLastError());
+    return S2S_OK;
+}
+
+int s2s_philox_u32(s2s_handle* h, void* stream_, uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                   int32_t n, uint32_t* out) {
+    if (!h) return S2S_ERR_ARG;
+    if (n < 0 || !out) return fail(h, S2S_ERR_ARG, "bad argument");
+    if (n == 0) return S2S_OK;
+    hipLaunchKernelGGL(s2s_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       (unsigned)seed, (unsigned)(seed >> 32), c0, c1, c2, c3, n, out);
+    HIP_TRY(h, hipGetLastError());
+    return S2S_OK;
+}
+
+int s2s_set_profiling(s2s_handle* h, int32_t enabled) {
+    if (!h) return S2S_ERR_ARG;
+    h->profiling = enabled != 0;
+    return S2S_OK;
+}
+
+int s2s_get_kernel_ms(s2s_handle* h, double* ms_total, int64_t* launches, int64_t* chunks) {
+    if (!h) return S2S_ERR_ARG;
+    double tot = 0.0;
+    int64_t nl = 0, nc = 0;
+    for (auto& ev : h->events) {
+        HIP_TRY(h, hipEventSynchronize(ev.b));
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, ev.a, ev.b));
+        tot += ms; nl += 1; nc += ev.chunks;
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+    }
+    h->events.clear();
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = nl;
+    if (chunks) *chunks = nc;
+    return S2S_OK;
+}
+
+}  // extern "C"

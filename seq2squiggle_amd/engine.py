@@ -1,0 +1,164 @@
+"""Engine: the Python face of the C ABI (include/s2s_hip.h).
+
+PyTorch is used for device memory and streams only: tensors are allocated with torch on the
+engine's device and handed to the library as raw pointers; launches go to torch's current
+stream so they order with the caller's other work.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .checkpoint import config_to_c, load_checkpoint, state_dict_to_blob
+
+T_ENC, T_DEC = 16, 250
+
+
+@dataclass
+class PredictParams:
+    """The scalars predict_step reads from the reference LightningModule (model.py:55-63)."""
+    dwell_mean: float = 12.5
+    dwell_std: float = 0.0
+    noise_std: float = 2.0
+    noise_sampling: bool = True
+    duration_sampling: bool = True
+    min_noise: float = 0.0
+    min_duration: float = 3.0
+    seed: int = 0
+
+    def to_c(self) -> "_lib.S2SParams":
+        return _lib.S2SParams(float(self.dwell_mean), float(self.dwell_std), float(self.noise_std),
+                              float(self.min_noise), float(self.min_duration), int(bool(self.noise_sampling)),
+                              int(bool(self.duration_sampling)), int(self.seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Weights resident on one GPU + the predict / export entry points."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: dict, device: Optional[int] = None):
+        self._h = None
+        L = _lib.lib()                       # raises when the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("seq2squiggle_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.config = dict(config)
+        self.k = int(config["seq_kmer"])
+        ccfg = config_to_c(config)
+        blob = np.ascontiguousarray(state_dict_to_blob(state_dict, config))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            rc = L.s2s_create(C.byref(ccfg), blob.ctypes.data_as(C.c_void_p), blob.nbytes, self.device_index, C.byref(h))
+        if rc != 0:
+            raise ValueError(f"s2s_create failed ({rc}): {L.s2s_last_error(None).decode()}")
+        self._h = h
+
+    @classmethod
+    def from_checkpoint(cls, path: str, device: Optional[int] = None) -> "Engine":
+        sd, cfg = load_checkpoint(path)
+        return cls(sd, cfg, device)
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().s2s_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {_lib.lib().s2s_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ predict
+    def predict_chunks(self, bases: torch.Tensor, n_valid: torch.Tensor, params: PredictParams,
+                       first_global_chunk: int = 0, inject_g: Optional[torch.Tensor] = None,
+                       inject_zdw: Optional[torch.Tensor] = None, inject_z01: Optional[torch.Tensor] = None,
+                       debug: bool = False, out_signal: Optional[torch.Tensor] = None,
+                       out_dur: Optional[torch.Tensor] = None):
+        """bases uint8 [B, 16+k-1] and n_valid uint8 [B] on the engine's device ->
+        dict(signal fp32 [B,250] pA, dur int32 [B,16] [, debug stage tensors])."""
+        B = int(bases.shape[0])
+        nb = T_ENC + self.k - 1
+        if bases.dtype != torch.uint8 or bases.dim() != 2 or bases.shape[1] != nb or not bases.is_contiguous():
+            raise ValueError(f"bases must be contiguous uint8 [B, {nb}]")
+        if n_valid.dtype != torch.uint8 or n_valid.shape != (B,) or not n_valid.is_contiguous():
+            raise ValueError("n_valid must be contiguous uint8 [B]")
+        for name, t, shape in (("inject_g", inject_g, (B, T_ENC)), ("inject_zdw", inject_zdw, (B, T_ENC)),
+                               ("inject_z01", inject_z01, (B, T_DEC))):
+            if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous()
+                                  or t.device != self.device):
+                raise ValueError(f"{name} must be contiguous float32 {shape} on {self.device}")
+        if bases.device != self.device or n_valid.device != self.device:
+            raise ValueError(f"inputs must live on {self.device}")
+        sig = out_signal if out_signal is not None else torch.empty(B, T_DEC, dtype=torch.float32, device=self.device)
+        dur = out_dur if out_dur is not None else torch.empty(B, T_ENC, dtype=torch.int32, device=self.device)
+        out = {"signal": sig, "dur": dur}
+        dbg = None
+        if debug:
+            f = dict(dtype=torch.float32, device=self.device)
+            out.update(emb_out=torch.zeros(B, 16, 64, **f), enc_out=torch.zeros(B, 16, 64, **f),
+                       sigma=torch.zeros(B, 16, **f), conc=torch.zeros(B, 16, **f), rate=torch.zeros(B, 16, **f),
+                       g=torch.zeros(B, 16, **f), y_scaled=torch.zeros(B, T_DEC, **f), z01=torch.zeros(B, T_DEC, **f))
+            dbg = _lib.S2SDebug(*[out[n].data_ptr() for n in ("emb_out", "enc_out", "sigma", "conc", "rate", "g",
+                                                              "y_scaled", "z01")])
+        p = params.to_c()
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().s2s_predict_chunks(self._h, self._stream(), _ptr(bases), _ptr(n_valid),
+                                               int(first_global_chunk), B, C.byref(p), _ptr(inject_g), _ptr(inject_zdw),
+                                               _ptr(inject_z01), _ptr(sig), _ptr(dur), C.byref(dbg) if dbg else None)
+        self._check(rc, "s2s_predict_chunks")
+        return out
+
+    # ------------------------------------------------------------------ export
+    def export_reads(self, signal: torch.Tensor, read_first: torch.Tensor, digitisation: float = 0.0,
+                     signal_range: float = 1.0, offset_mean: float = 0.0, rna: bool = False, want_pa: bool = True,
+                     want_dac: bool = False):
+        """Per-read zero-strip (model.py:284-286) and optional int16 conversion (signal_io.py:134-141) on
+        the GPU.  signal [B,250]; read_first int32 [R+1] -> dict(offsets int64 [R+1], pa, dac)."""
+        B, R = int(signal.shape[0]), int(read_first.shape[0]) - 1
+        if signal.dtype != torch.float32 or not signal.is_contiguous() or signal.shape[1] != T_DEC:
+            raise ValueError("signal must be contiguous float32 [B,250]")
+        if read_first.dtype != torch.int32 or not read_first.is_contiguous():
+            raise ValueError("read_first must be contiguous int32 [R+1]")
+        offs = torch.empty(R + 1, dtype=torch.int64, device=self.device)
+        cap = B * T_DEC
+        pa = torch.empty(cap, dtype=torch.float32, device=self.device) if want_pa else None
+        dac = torch.empty(cap, dtype=torch.int16, device=self.device) if want_dac else None
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().s2s_export_reads(self._h, self._stream(), _ptr(signal), B, _ptr(read_first), R, _ptr(offs),
+                                             _ptr(pa), _ptr(dac), cap, float(digitisation), float(signal_range),
+                                             float(offset_mean), int(bool(rna)))
+        self._check(rc, "s2s_export_reads")
+        return {"offsets": offs, "pa": pa, "dac": dac}
+
+    # ------------------------------------------------------------------ misc
+    def philox_u32(self, seed: int, c0: int, c1: int, c2: int, c3: int, n: int) -> torch.Tensor:
+        out = torch.empty(n, 4, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().s2s_philox_u32(self._h, self._stream(), int(seed), c0, c1, c2, c3, n, _ptr(out))
+        self._check(rc, "s2s_philox_u32")
+        return out
+
+    def set_profiling(self, enabled: bool):
+        self._check(_lib.lib().s2s_set_profiling(self._h, int(enabled)), "s2s_set_profiling")
+
+    def kernel_ms(self):
+        """-> (total decoder-kernel ms, launches, chunks) since the last call (HIP events on the launch stream)."""
+        ms, nl, nc = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(_lib.lib().s2s_get_kernel_ms(self._h, C.byref(ms), C.byref(nl), C.byref(nc)), "s2s_get_kernel_ms")
+        return ms.value, nl.value, nc.value

@@ -1,0 +1,214 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
+
+Tolerances (floating point path; stated per BASELINE.json north_star):
+  * dwell indices: bit-exact;
+  * zero pattern of the signal (ReLU zeros / pad / clamp): exact;
+  * signal: MAE < 1e-4 pA vs the fp32 reference goldens, max |diff| < 2e-3 pA.
+"""
+import numpy as np
+import pytest
+import torch
+
+import seq2squiggle_amd as S
+from seq2squiggle_amd import chunker
+from oracle import s2s_oracle as O
+from conftest import load_ckpt, load_npz
+
+pytestmark = pytest.mark.gpu
+MAE_TOL, MAX_TOL = 1e-4, 2e-3
+
+
+def P(**kw):
+    base = dict(dwell_mean=12.5, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
+                min_noise=0.0, min_duration=3.0)
+    base.update(kw)
+    return base
+
+
+@pytest.fixture(scope="module", params=["k9", "k6"])
+def case(request):
+    tag = request.param
+    sd, cfg = load_ckpt(tag)
+    eng = S.Engine(sd, cfg)
+    g = load_npz(f"stages_{tag}.npz")
+    bases, nv = chunker.codes_to_bases(g["codes"])
+    dev = eng.device
+    yield dict(tag=tag, sd=sd, cfg=cfg, eng=eng, g=g, bases=torch.from_numpy(bases).to(dev),
+               nv=torch.from_numpy(nv).to(dev), dev=dev)
+    eng.close()
+
+
+def dev_t(case, key):
+    return torch.from_numpy(np.ascontiguousarray(case["g"][key])).to(case["dev"])
+
+
+def test_stage_outputs(case):
+    g, eng = case["g"], case["eng"]
+    out = eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(**P(noise_std=0.0)),
+                             inject_g=dev_t(case, "g"), debug=True)
+    torch.cuda.synchronize()
+    assert np.abs(out["emb_out"].cpu().numpy() - g["emb_out"]).max() < 2e-6
+    assert np.abs(out["enc_out"].cpu().numpy() - g["enc_out"]).max() < 2e-5
+    assert np.abs(out["sigma"].cpu().numpy() - g["sigma"]).max() < 2e-6
+    assert np.allclose(out["conc"].cpu().numpy(), g["conc"], rtol=2e-6, atol=2e-6)
+    assert np.allclose(out["rate"].cpu().numpy(), g["rate"], rtol=2e-6, atol=2e-6)
+    assert np.array_equal(out["dur"].cpu().numpy(), g["dur_gamma"])
+    assert np.abs(out["y_scaled"].cpu().numpy() - g["y_scaled_gamma"]).max() < 2e-5
+
+
+CASES = [
+    ("y_gamma_nsamp", dict(), True, True, False),
+    ("y_gamma_nsamp_minnoise", dict(noise_std=1.5, min_noise=0.02), True, True, False),
+    ("y_gamma_nconst", dict(noise_sampling=False), True, True, False),
+    ("y_gamma_nonoise", dict(noise_std=0.0), True, False, False),
+    ("y_ideal", dict(noise_std=0.0, noise_sampling=False, duration_sampling=False), False, False, False),
+    ("y_ideal_nsamp", dict(duration_sampling=False), False, True, False),
+    ("y_normal_nsamp", dict(duration_sampling=False, dwell_std=4.0), False, True, True),
+    ("y_ideal_dwell31", dict(noise_std=0.0, noise_sampling=False, duration_sampling=False,
+                             dwell_mean=4000 / 130), False, False, False),
+]
+
+
+@pytest.mark.parametrize("key,over,use_g,use_z,use_zdw", CASES)
+def test_predict_modes_vs_reference_goldens(case, key, over, use_g, use_z, use_zdw):
+    g, eng = case["g"], case["eng"]
+    out = eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(**P(**over)),
+                             inject_g=dev_t(case, "g") if use_g else None,
+                             inject_z01=dev_t(case, "z01") if use_z else None,
+                             inject_zdw=dev_t(case, "zdw") if use_zdw else None)
+    y, ref = out["signal"].cpu().numpy(), g[key]
+    assert np.array_equal(y == 0, ref == 0)
+    d = np.abs(y - ref)
+    assert d.mean() < MAE_TOL and d.max() < MAX_TOL, (d.mean(), d.max())
+    if key == "y_normal_nsamp":
+        assert np.array_equal(out["dur"].cpu().numpy(), g["dur_normal"])
+    if key == "y_ideal":
+        assert (out["dur"].cpu().numpy() == 12).all()
+
+
+def test_random_batch_vs_oracle(case):
+    """Seeded random chunks (with N and short tails) at a size the oracle does in seconds."""
+    k, eng, dev = case["cfg"]["seq_kmer"], case["eng"], case["dev"]
+    rng = np.random.default_rng(42)
+    reads = ["".join(rng.choice(list("ACGTN"), int(n), p=[.245, .245, .245, .245, .02]))
+             for n in rng.integers(k, 400, size=40)]
+    bases, nv, first = S.encode_reads(reads, k)
+    codes = np.concatenate([O.encode_read(r, k) for r in reads], 0)
+    B = bases.shape[0]
+    gen = torch.Generator().manual_seed(3)
+    ginj = (torch.rand(B, 16, generator=gen) * 25).float()
+    z = torch.randn(B, 250, generator=gen)
+    p = P()
+    ref = O.predict_chunks(case["sd"], case["cfg"], codes, O.PredictParams(**p), inject_g=ginj, inject_z01=z)
+    out = eng.predict_chunks(torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev), S.PredictParams(**p),
+                             inject_g=ginj.to(dev), inject_z01=z.to(dev))
+    assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
+    y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
+    assert np.array_equal(y == 0, r == 0)
+    assert np.abs(y - r).mean() < MAE_TOL and np.abs(y - r).max() < MAX_TOL
+
+
+def test_closer_to_fp64_truth_than_tolerance(case):
+    """Report-style: distance to an fp64 evaluation of the same model is at the fp32 noise floor."""
+    g, eng = case["g"], case["eng"]
+    p = P(noise_std=0.0)
+    o64 = O.predict_chunks(case["sd"], case["cfg"], g["codes"], O.PredictParams(**p),
+                           inject_g=torch.from_numpy(g["g"]), dtype=torch.float64)
+    out = eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(**p), inject_g=dev_t(case, "g"))
+    y = out["signal"].cpu().numpy().astype(np.float64)
+    t = o64["signal"].numpy()
+    same = (y == 0) == (t == 0)
+    assert same.mean() > 0.999
+    assert np.abs(y - t)[same].mean() < MAE_TOL
+
+
+def test_batch_and_offset_invariance(case):
+    """Counter-based RNG: the same chunk gives the same samples whatever the batch split."""
+    eng = case["eng"]
+    pp = S.PredictParams(**P(seed=1234))
+    full = eng.predict_chunks(case["bases"], case["nv"], pp, first_global_chunk=1000)
+    s = 17
+    a = eng.predict_chunks(case["bases"][:s].contiguous(), case["nv"][:s].contiguous(), pp, first_global_chunk=1000)
+    b = eng.predict_chunks(case["bases"][s:].contiguous(), case["nv"][s:].contiguous(), pp, first_global_chunk=1000 + s)
+    assert torch.equal(full["signal"], torch.cat([a["signal"], b["signal"]]))
+    assert torch.equal(full["dur"], torch.cat([a["dur"], b["dur"]]))
+    other = eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(**P(seed=1235)), first_global_chunk=1000)
+    assert not torch.equal(full["dur"], other["dur"])
+
+
+def test_empty_batch_and_bad_args(case):
+    eng, dev = case["eng"], case["dev"]
+    nb = 16 + case["cfg"]["seq_kmer"] - 1
+    out = eng.predict_chunks(torch.zeros(0, nb, dtype=torch.uint8, device=dev), torch.zeros(0, dtype=torch.uint8, device=dev),
+                             S.PredictParams())
+    assert out["signal"].shape == (0, 250)
+    with pytest.raises(ValueError):
+        eng.predict_chunks(torch.zeros(2, nb + 1, dtype=torch.uint8, device=dev), torch.zeros(2, dtype=torch.uint8, device=dev),
+                           S.PredictParams())
+    with pytest.raises(RuntimeError):
+        eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(min_duration=-1.0))
+
+
+def test_philox_known_answers(case):
+    eng = case["eng"]
+    # Random123 kat_vectors: philox4x32-10
+    r = eng.philox_u32(0, 0, 0, 0, 0, 1).cpu().numpy().view(np.uint32)[0]
+    assert [hex(x) for x in r] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    r = eng.philox_u32(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 1).cpu().numpy().view(np.uint32)[0]
+    assert [hex(x) for x in r] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_sampler_statistics(case):
+    """Built-in Philox samplers vs torch's own Gamma / Normal at the same parameters."""
+    eng, dev, k = case["eng"], case["dev"], case["cfg"]["seq_kmer"]
+    rng = np.random.default_rng(0)
+    reads = ["".join(rng.choice(list("ACGT"), 16 * 64 + k - 1))]
+    bases, nv, _ = S.encode_reads(reads * 64, k)
+    bt, nvt = torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev)
+    out = eng.predict_chunks(bt, nvt, S.PredictParams(**P(min_duration=0.0, seed=7)), debug=True)
+    conc, rate, gd = out["conc"].cpu(), out["rate"].cpu(), out["g"].cpu()
+    gen = torch.Generator().manual_seed(1)
+    ref = (torch._standard_gamma(conc, generator=gen) / rate).clamp(min=1.0)
+    # the 64 copies of the read share conc/rate per position but have distinct chunk counters
+    assert abs(gd.mean().item() - ref.mean().item()) < 0.05 * ref.mean().item()
+    assert abs(gd.std().item() - ref.std().item()) < 0.08 * ref.std().item()
+    qs = torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9])
+    assert torch.allclose(torch.quantile(gd.flatten(), qs), torch.quantile(ref.flatten(), qs), rtol=0.06)
+    z = out["z01"].cpu().flatten()
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1.0) < 0.01
+    assert abs((z ** 4).mean().item() - 3.0) < 0.15
+    # noise really is N(0, sd): signal - noiseless signal, normalised, where the noiseless sample is non-zero
+    clean = eng.predict_chunks(bt, nvt, S.PredictParams(**P(min_duration=0.0, seed=7, noise_std=0.0)))
+    assert torch.equal(clean["dur"], out["dur"])
+
+
+def test_export_zero_strip_and_dac(case):
+    tag, g, eng, dev = case["tag"], case["g"], case["eng"], case["dev"]
+    sig = load_npz(f"signals_{tag}.npz")
+    out = eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(**P()), inject_g=dev_t(case, "g"),
+                             inject_z01=dev_t(case, "z01"))
+    names = [str(n) for n in g["names"]]
+    order = [str(n) for n in sig["read_order"]]
+    first = [0]
+    for rid in order:
+        first.append(first[-1] + names.count(rid))
+    rf = torch.tensor(first, dtype=torch.int32, device=dev)
+    prof = load_npz("profiles.npz")
+    pname = "dna-r10-prom" if tag == "k9" else "dna-r9-min"
+    dig, _, _, rng_, off = prof[pname + "__profile"][:5]
+    ex = eng.export_reads(out["signal"], rf, dig, rng_, off, rna=False, want_pa=True, want_dac=True)
+    offs = ex["offsets"].cpu().numpy()
+    pa, dac = ex["pa"].cpu().numpy(), ex["dac"].cpu().numpy()
+    host_sig = out["signal"].cpu()
+    for r, rid in enumerate(order):
+        ref = sig["sig__" + rid]
+        got = pa[offs[r]:offs[r + 1]]
+        assert got.shape == ref.shape, rid
+        assert np.abs(got - ref).max() < MAX_TOL
+        mine = O.strip_zeros([host_sig[i] for i in range(first[r], first[r + 1])]).numpy()
+        assert np.array_equal(got, mine)                      # compaction itself is exact
+        assert np.array_equal(dac[offs[r]:offs[r + 1]], O.to_dac(mine, dig, rng_, off))
+    exr = eng.export_reads(out["signal"], rf, dig, rng_, off, rna=True, want_pa=False, want_dac=True)
+    dr = exr["dac"].cpu().numpy()
+    for r in range(len(order)):
+        assert np.array_equal(dr[offs[r]:offs[r + 1]], dac[offs[r]:offs[r + 1]][::-1])
