@@ -270,7 +270,9 @@ def to_dac(signal: np.ndarray, digitisation: float, signal_range: float, offset_
            rna: bool = False) -> np.ndarray:
     """pA -> int16 (signal_io.py:134-141): round-half-even of float32 expr, C cast to int16 (wraps)."""
     s = np.asarray(signal, dtype=np.float32)
-    raw = np.round(s * digitisation / signal_range - offset_mean)
+    # the reference multiplies a float32 array by python floats: float32 arithmetic throughout
+    raw = np.round(s * float(digitisation) / float(signal_range) - float(offset_mean))
+    assert raw.dtype == np.float32
     raw = raw.astype(np.int64).astype(np.int16)  # wrap like the reference's astype(np.int16) on x86
     if rna:
         raw = np.ascontiguousarray(raw[::-1])
