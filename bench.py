@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the predict hot path on MI355X (contract: see the task statement).
+
+A "step" is one pass of the hot path (s2s_predict_chunks: frontend + decoder kernels) over one
+batch of synthetic reads already resident in HBM.  Workload at N=1 (BASELINE.json configs[1]
+shape): 1000 reads x 5000 nt = 312,000 chunks, default noise + duration samplers (noise_std 2.0,
+min_duration 3), synthetic k=9 checkpoint.  With N>1 every rank runs the same amount of work on
+its own read shard (weak scaling, no data-path collective); RCCL is used only for the barrier
+and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import seq2squiggle_amd as S  # noqa: E402
+
+FLOP_PER_CHUNK = 85_083_392            # 2 x 42,541,696 MAC, k = 9
+FLOP_PER_CHUNK_DECODER = 2 * 40_592_000  # decoder-side share (the dominant kernel), SURVEY.md section 2.2
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
+READ_LEN, CHUNKS_PER_READ = 5000, 312
+
+
+def make_reads(n_reads, seed):
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, size=(n_reads, READ_LEN), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    return [lut[c].tobytes().decode() for c in codes]
+
+
+def cpu_baseline(sd, cfg, seconds_target=12.0):
+    """Oracle (CPU port of the reference op sequence, torch fp32 'highest') on the host cores."""
+    from oracle import s2s_oracle as O
+    torch.set_float32_matmul_precision("highest")
+    reads = make_reads(4, 99)
+    codes = np.concatenate([O.encode_read(r, cfg["seq_kmer"]) for r in reads], 0)[:1024]
+    p = O.PredictParams()
+    gen = torch.Generator().manual_seed(0)
+    O.predict_chunks(sd, cfg, codes[:64], p, generator=gen)            # warm-up
+    t0, done = time.perf_counter(), 0
+    while True:
+        O.predict_chunks(sd, cfg, codes, p, generator=gen)
+        done += codes.shape[0]
+        el = time.perf_counter() - t0
+        if el >= seconds_target or done >= 8 * 1024:
+            break
+    return {"value": done * 250 / el, "unit": "samples/s", "cores": len(os.sched_getaffinity(0)),
+            "torch_threads": torch.get_num_threads(), "kind": "port",
+            "reads_per_sec": done / CHUNKS_PER_READ / el,
+            "sample": f"{done} chunks (batches of 1024, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
+    eng = S.Engine(sd, cfg, device=local)
+    dev = eng.device
+    reads = make_reads(a.reads, 1234 + rank)               # every rank: its own shard of the read set
+    bases, nv, first = S.encode_reads(reads, cfg["seq_kmer"])
+    B = bases.shape[0]
+    bases_d, nv_d = torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev)
+    sig = torch.empty(B, 250, dtype=torch.float32, device=dev)
+    dur = torch.empty(B, 16, dtype=torch.int32, device=dev)
+    params = S.PredictParams(seed=42)                      # defaults: noise_std 2.0, samplers on, min_duration 3
+    first_chunk = rank * B
+
+    def step():
+        eng.predict_chunks(bases_d, nv_d, params, first_global_chunk=first_chunk, out_signal=sig, out_dur=dur)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    eng.set_profiling(False)
+    dec_ms, dec_launches, dec_chunks = eng.kernel_ms()
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    emitted = int((sig != 0).sum().item())
+
+    if rank == 0:
+        chunks_total = B * a.steps * world
+        chunks_s = chunks_total / el
+        tflops = FLOP_PER_CHUNK_DECODER * dec_chunks / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else None
+        out = {
+            "metric": "signal samples/sec at 5 kb reads (padded [chunks x 250] samples the predict path emits)",
+            "value": chunks_s * 250, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.reads} synthetic reads x {READ_LEN} nt per GPU ({B} chunks/step/GPU), "
+                                   "default noise+duration samplers, synthetic k=9 checkpoint",
+                       "chunks_per_step_per_gpu": B, "profile": "dna-r10-prom", "seed": 42},
+            "reads_per_sec": chunks_s / CHUNKS_PER_READ, "chunks_per_sec": chunks_s,
+            "emitted_samples_per_sec": emitted * world / (el / a.steps),
+            "roofline": {"bound": "mfma", "kernel": "s2s_decoder_kernel", "achieved": tflops,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (tflops / PEAK_F32_MFMA_TFLOPS) if tflops else None, "traffic": None,
+                         "flop_per_chunk": FLOP_PER_CHUNK_DECODER,
+                         "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
+                         "launches": dec_launches, "chunks_per_launch": dec_chunks / dec_launches if dec_launches else None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, cfg)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    eng.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

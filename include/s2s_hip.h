@@ -151,6 +151,10 @@ int s2s_set_profiling(s2s_handle* h, int32_t enabled);
 int s2s_get_kernel_ms(s2s_handle* h, double* decoder_ms_total, int64_t* decoder_launches,
                       int64_t* decoder_chunks);
 
+/* Diagnostic builds (-DS2S_DIAG, never the shipped library): per-phase wave-cycle sums of the
+ * decoder kernel since the last call; S2S_ERR_ARG in a normal build. */
+int s2s_diag_read(s2s_handle* h, uint64_t* out16);
+
 #ifdef __cplusplus
 }
 #endif

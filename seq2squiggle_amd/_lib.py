@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 
-from ._build import LIB
+from ._build import LIB as _LIB_DEFAULT
 
 _lib = None
 
@@ -24,7 +24,7 @@ class S2SDebug(C.Structure):
 
 
 EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks",
-           "s2s_export_reads", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms")
+           "s2s_export_reads", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read")
 
 
 def lib():
@@ -32,6 +32,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    LIB = os.environ.get("S2S_HIP_LIB", _LIB_DEFAULT)   # diagnostic builds are selected explicitly
     if not os.path.exists(LIB):
         raise RuntimeError(f"HIP extension not built: {LIB} is missing (run __graft_entry__.build()); "
                            "there is no CPU fallback for the predict path")
@@ -56,5 +57,7 @@ def lib():
     L.s2s_set_profiling.argtypes = [vp, i32]
     L.s2s_get_kernel_ms.restype = i32
     L.s2s_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
+    L.s2s_diag_read.restype = i32
+    L.s2s_diag_read.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L

@@ -17,7 +17,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define S2S_MAX_LAYERS 4
 
 struct LayerOff {
-    int wq, wk, wv, wfc, w1, w2;            // packed A fragments (float offsets into the arena)
+    int stream;                             // packed A fragments in consumption order (float offset into the arena)
     int bq, bk, bv, bfc, b1, b2;            // biases (bq/bk in the q/k row permutation)
     int ln1g, ln1b, ln2g, ln2b;
 };
@@ -39,7 +39,24 @@ struct ParamsDev {
 };
 struct DebugDev {
     float *emb_out, *enc_out, *sigma, *conc, *rate, *g, *y_scaled, *z01;
+    unsigned long long* diag;       // S2S_DIAG builds only
 };
+
+#ifdef S2S_DIAG
+// diagnostic build only: per-phase wave-cycle sums (s_memtime) into a side buffer no other code reads
+#define DIAG_DECL unsigned long long diag_t_ = clock64()
+#define DIAG_STAMP(slot)                                                            \
+    do {                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        const unsigned long long n_ = clock64();                                    \
+        if (diag_buf && (threadIdx.x & 63) == 0) atomicAdd(diag_buf + (slot), n_ - diag_t_); \
+        diag_t_ = n_;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#else
+#define DIAG_DECL
+#define DIAG_STAMP(slot)
+#endif
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -165,6 +182,24 @@ __device__ __forceinline__ void layer_norm64(f32x4 (&x)[NQ][4], const float* __r
     }
 }
 
+// One weight "unit" = 4 A fragments (4 KiB) = what one 16-row m-tile of a K=64 GEMM consumes.
+// A layer's units are stored in the order the block consumes them (host: pack_layer), so the
+// stream pointer just advances and the next unit is always requested one unit ahead of its use.
+__device__ __forceinline__ void load_unit(f32x4 (&f)[4], const float* __restrict__ ws) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = ldg4(ws + i * 256);
+}
+// acc[q] += W_unit * x[q]   (one m-tile, k-tiles 0..3)
+template <int NQ>
+__device__ __forceinline__ void mm_unit(f32x4 (&acc)[NQ], const f32x4 (&f)[4], const f32x4 (&x)[NQ][4]) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = MFMA4(f[kt][r], x[q][kt][r], acc[q]);
+}
+
 // One FFTBlock (layers.py:116-142): post-LN multi-head attention (layers.py:44-88, 11-41; no
 // mask in predict, model.py:217) + position-wise FFN (layers.py:91-113), eval mode.
 //   X    : this wave's NQ time tiles of the block input, replaced by the block output;
@@ -173,32 +208,43 @@ __device__ __forceinline__ void layer_norm64(f32x4 (&x)[NQ][4], const float* __r
 //   TV   : number of real keys (keys >= TV are phantom padding and get probability 0).
 template <int NQ, int NKT, int TV>
 __device__ __forceinline__ void fft_block(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
-                                          float* __restrict__ lds, int qt0, int lane) {
+                                          float* __restrict__ lds, int qt0, int lane,
+                                          unsigned long long* diag_buf = nullptr) {
     using G = AttnLds<NKT>;
+    DIAG_DECL;
     const int g = lane >> 4, c = lane & 15;
     f32x2* __restrict__ Kl = reinterpret_cast<f32x2*>(lds);
     float* __restrict__ Vl = lds + G::K_FLOATS;
     const float* __restrict__ Zl = Vl + G::V_FLOATS;
+    const float* ws = W + L.stream + lane * 4;       // weight stream, this lane's slice of each fragment
+    f32x4 fa[4], fb[4];                               // ping-pong unit buffers
 
-    __syncthreads();                       // every wave is done reading the previous block's K/V
+    load_unit(fa, ws); ws += 1024;                    // Wk, pair 0
+    __syncthreads();
+    DIAG_STAMP(0);                                  // every wave is done reading the previous block's K/V
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS (layers.py:74-78)
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
-        f32x4 ak[NQ][1], av[NQ][1];
+        load_unit(fb, ws); ws += 1024;                // Wv, pair p
         const f32x4 bk = ldg4(W + L.bk + 16 * p + 4 * g), bv = ldg4(W + L.bv + 16 * p + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 ak[NQ], av[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { ak[q][0] = bk; av[q][0] = bv; }
-        gemm_acc<NQ, 1, 4>(W + L.wk + p * 4 * 256, lane, ak, X);
-        gemm_acc<NQ, 1, 4>(W + L.wv + p * 4 * 256, lane, av, X);
+        for (int q = 0; q < NQ; ++q) { ak[q] = bk; av[q] = bv; }
+        mm_unit<NQ>(ak, fa, X);
+        __builtin_amdgcn_sched_barrier(0);
+        load_unit(fa, ws); ws += 1024;                // Wk, pair p+1 (after the last pair: Wq, pair 0)
+        __builtin_amdgcn_sched_barrier(0);
+        mm_unit<NQ>(av, fb, X);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int key = 16 * (qt0 + q) + c;
             // rows of the packed Wk tile are permuted so that registers {0,1} are head 2p
             // (d = 2g, 2g+1) and registers {2,3} head 2p+1: exactly the float2 the S MFMA reads
-            Kl[((2 * p + 0) * 4 + g) * G::KPS + key] = f32x2{ak[q][0][0], ak[q][0][1]};
-            Kl[((2 * p + 1) * 4 + g) * G::KPS + key] = f32x2{ak[q][0][2], ak[q][0][3]};
+            Kl[((2 * p + 0) * 4 + g) * G::KPS + key] = f32x2{ak[q][0], ak[q][1]};
+            Kl[((2 * p + 1) * 4 + g) * G::KPS + key] = f32x2{ak[q][2], ak[q][3]};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Vl[(p * 16 + 4 * g + r) * G::RS + key] = av[q][0][r];
+            for (int r = 0; r < 4; ++r) Vl[(p * 16 + 4 * g + r) * G::RS + key] = av[q][r];
         }
     }
     if (qt0 == 0 && lane < G::Z_FLOATS / 4)      // zero strip (<= 64 float4)
@@ -212,19 +258,20 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
+    DIAG_STAMP(1);
     __syncthreads();                       // K/V of every wave visible
+    DIAG_STAMP(2);
 
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
-        // Q^T of head pair p for this wave's time tiles (same row permutation as K)
-        f32x4 qp[NQ][1];
-        {
-            const f32x4 bq = ldg4(W + L.bq + 16 * p + 4 * g);
+        const f32x4 bq = ldg4(W + L.bq + 16 * p + 4 * g);
+        // Q^T of head pair p for this wave's time tiles (same row permutation as K); fa = Wq rows of p
+        f32x4 qp[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) qp[q][0] = bq;
-            gemm_acc<NQ, 1, 4>(W + L.wq + p * 4 * 256, lane, qp, X);
-        }
+        for (int q = 0; q < NQ; ++q) qp[q] = bq;
+        mm_unit<NQ>(qp, fa, X);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 op[NQ];                      // O^T of the pair: rows 0-7 head 2p, rows 8-15 head 2p+1
 #pragma unroll
         for (int q = 0; q < NQ; ++q) op[q] = f32x4{0, 0, 0, 0};
@@ -235,11 +282,20 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 f32x4 s[NKT];
+                const float q0 = qp[q][2 * hh], q1 = qp[q][2 * hh + 1];
+                if (NKT == 1) {
+                    const f32x2 a = kp[0];
+                    s[0] = MFMA4(a[0], q0, (f32x4{0, 0, 0, 0}));
+                    s[0] = MFMA4(a[1], q1, s[0]);
+                } else {
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    const f32x2 a = kp[16 * kt];
-                    s[kt] = MFMA4(a[0], qp[q][0][2 * hh], (f32x4{0, 0, 0, 0}));
-                    s[kt] = MFMA4(a[1], qp[q][0][2 * hh + 1], s[kt]);
+                    for (int kt = 0; kt + 1 < NKT; kt += 2) {      // two tiles interleaved: no back-to-back dependent MFMA
+                        const f32x2 a0 = kp[16 * kt], a1 = kp[16 * kt + 16];
+                        s[kt] = MFMA4(a0[0], q0, (f32x4{0, 0, 0, 0}));
+                        s[kt + 1] = MFMA4(a1[0], q0, (f32x4{0, 0, 0, 0}));
+                        s[kt] = MFMA4(a0[1], q1, s[kt]);
+                        s[kt + 1] = MFMA4(a1[1], q1, s[kt + 1]);
+                    }
                 }
                 if (TV < 16 * NKT) {       // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
@@ -263,31 +319,37 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
                         l += e;
                     }
                 l = sum_g(l);
+                if (hh == 1 && q == NQ - 1) {
+                    // the pair's last P.V (64 MFMAs) covers the latency of the next two weight units:
+                    // Wfc columns of pair p, then Wq rows of pair p+1 (after the last pair: W1 unit 0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_unit(fb, ws); load_unit(fa, ws + 1024); ws += 2048;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 f32x4 o0 = f32x4{0, 0, 0, 0}, o1 = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 16 * kt);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (kt & 1) o1 = MFMA4(a[r], s[kt][r], o1);
-                        else        o0 = MFMA4(a[r], s[kt][r], o0);
-                    }
+                    o0 = MFMA4(a[0], s[kt][0], o0);
+                    o1 = MFMA4(a[1], s[kt][1], o1);
+                    o0 = MFMA4(a[2], s[kt][2], o0);
+                    o1 = MFMA4(a[3], s[kt][3], o1);
                 }
                 const float inv = 1.0f / l;
                 op[q] += (o0 + o1) * inv;  // the other head's rows are exact zeros
             }
         }
-        // fc: acc += Wfc[:, 16p : 16p+16] * O_pair^T
+        // fc: acc += Wfc[:, 16p : 16p+16] * O_pair^T   (unit = the 4 m-tiles of k-tile p)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 a = ldg4(W + L.wfc + ((mt * 4 + p) * 64 + lane) * 4);
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMA4(a[r], op[q][r], acc[q][mt]);
-        }
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMA4(fb[mt][r], op[q][r], acc[q][mt]);
     }
+    DIAG_STAMP(3);
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+    DIAG_STAMP(4);
 
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
 #pragma unroll
@@ -299,31 +361,35 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
 #pragma unroll 1
     for (int hc = 0; hc < 4; ++hc) {
         f32x4 hid[NQ][4];
+        f32x4 b1[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 b = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
+        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) hid[q][mt] = b;
+        for (int mt = 0; mt < 4; ++mt) {              // W1 units: rows 64hc + 16mt ..
+            f32x4 t[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[q] = b1[mt];
+            if (mt & 1) { load_unit(fa, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit<NQ>(t, fb, acc); }
+            else        { load_unit(fb, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit<NQ>(t, fa, acc); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
         }
-        gemm_acc<NQ, 4, 4>(W + L.w1 + hc * 16 * 256, lane, hid, acc);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
+            f32x4 t[NQ];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
+            if (mt & 1) { load_unit(fa, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit<NQ>(t, fb, hid); }
+            else        { load_unit(fb, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit<NQ>(t, fa, hid); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(hid[q][mt][r], 0.0f);
-        // W2 packed [4 mt][16 kt]: this slice uses k-tiles 4hc .. 4hc+3
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 a = ldg4(W + L.w2 + ((mt * 16 + 4 * hc + kt) * 64 + lane) * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) X[q][mt] = MFMA4(a[r], hid[q][kt][r], X[q][mt]);
-            }
+            for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
         }
     }
+    DIAG_STAMP(5);
     layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+    DIAG_STAMP(6);
 }

@@ -169,6 +169,10 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     // ---- length regulator (modules.py:344-392) as a gather: row t copies encoder row
     //      i(t) = #{j : cum[j] <= t}; rows past cum[15] are zero; crop at 250; then + position_enc
     //      (modules.py:136, also on the zero rows)
+#ifdef S2S_DIAG
+    unsigned long long* diag_buf = dbg.diag;
+#endif
+    DIAG_DECL;
     int cum[16];
     {
         int run = 0;
@@ -193,11 +197,13 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
         }
         sig_ext[q] = live ? ws_sigma[b * 16 + (live ? idx : 0)] : 0.0f;
     }
+    DIAG_STAMP(8);
 #pragma unroll 1
-    for (int l = 0; l < M.dec_layers; ++l) fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane);
+    for (int l = 0; l < M.dec_layers; ++l) fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
 
     // ---- out_linear + ReLU (modules.py:140-141), x165 (model.py:221), noise where != 0
     //      (model.py:224-238), clamp (model.py:240)
+    DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
     f32x4 wo[4];
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) wo[ft] = ldg4(W + M.out_w + 16 * ft + 4 * g);
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
             out_signal[(size_t)b * S2S_T_DEC + t] = fmaxf(y, 0.0f);
         }
     }
+    DIAG_STAMP(9);
 }
 
 // ================================================================================ export
@@ -340,6 +347,7 @@ struct s2s_handle {
     long long* ws_offs = nullptr;
     int ws_export_cap = 0;
     bool profiling = false;
+    unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: 16 per-phase wave-cycle sums
     std::vector<EventPair> events;
     std::string err;
 };
@@ -419,12 +427,40 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     const float* w1 = take(p, 256 * 64); const float* b1 = take(p, 256);
     const float* w2 = take(p, 64 * 256); const float* b2 = take(p, 64);
     const float* ln2g = take(p, 64); const float* ln2b = take(p, 64);
-    L.wq = A.put_afrag(wq, 64, 64, true);   L.bq = A.put_bias_perm(bq, 64);
-    L.wk = A.put_afrag(wk, 64, 64, true);   L.bk = A.put_bias_perm(bk, 64);
-    L.wv = A.put_afrag(wv, 64, 64, false);  L.bv = A.put(bv, 64);
-    L.wfc = A.put_afrag(wfc, 64, 64, false); L.bfc = A.put(bfc, 64);
-    L.w1 = A.put_afrag(w1, 256, 64, false); L.b1 = A.put(b1, 256);
-    L.w2 = A.put_afrag(w2, 64, 256, false); L.b2 = A.put(b2, 64);
+    // weight stream in the order fft_block consumes it (one unit = 4 fragments = 4 KiB):
+    //   K/V phase : per head pair p: Wk rows of p (k-tiles 0..3), Wv rows of p
+    //   attention : per pair p: Wq rows of p, Wfc columns of p (m-tiles 0..3)
+    //   FFN       : per 64-wide hidden slice hc: W1 m-tiles 4hc..4hc+3, then W2 m-tiles 0..3 x k-tiles 4hc..4hc+3
+    std::vector<float> st;
+    auto frag = [&](const float* Wm, int K, int mt, int kt, bool perm) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, i = lane & 15;
+            const int row = 16 * mt + (perm ? Arena::perm16(i) : i);
+            for (int r = 0; r < 4; ++r) st.push_back(Wm[(size_t)row * K + 16 * kt + 4 * g + r]);
+        }
+    };
+    for (int p_ = 0; p_ < 4; ++p_) {
+        for (int kt = 0; kt < 4; ++kt) frag(wk, 64, p_, kt, true);
+        for (int kt = 0; kt < 4; ++kt) frag(wv, 64, p_, kt, false);
+    }
+    for (int p_ = 0; p_ < 4; ++p_) {
+        for (int kt = 0; kt < 4; ++kt) frag(wq, 64, p_, kt, true);
+        for (int mt = 0; mt < 4; ++mt) frag(wfc, 64, mt, p_, false);
+    }
+    for (int hc = 0; hc < 4; ++hc) {
+        for (int mt = 0; mt < 4; ++mt)
+            for (int kt = 0; kt < 4; ++kt) frag(w1, 64, 4 * hc + mt, kt, false);
+        for (int mt = 0; mt < 4; ++mt)
+            for (int kt = 0; kt < 4; ++kt) frag(w2, 256, mt, 4 * hc + kt, false);
+    }
+    st.resize(st.size() + 1024, 0.0f);       // the block's last prefetch reads one unit past its stream
+    L.stream = A.put(st.data(), st.size());
+    L.bq = A.put_bias_perm(bq, 64);
+    L.bk = A.put_bias_perm(bk, 64);
+    L.bv = A.put(bv, 64);
+    L.bfc = A.put(bfc, 64);
+    L.b1 = A.put(b1, 256);
+    L.b2 = A.put(b2, 64);
     L.ln1g = A.put(ln1g, 64); L.ln1b = A.put(ln1b, 64);
     L.ln2g = A.put(ln2g, 64); L.ln2b = A.put(ln2b, 64);
     return L;
@@ -527,6 +563,10 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  AttnLds<DEC_NKT>::BYTES)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute(decoder LDS)");
+#ifdef S2S_DIAG
+    if ((e = hipMalloc(&h->d_diag, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
+    if ((e = hipMemset(h->d_diag, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
+#endif
     *out = h;
     return S2S_OK;
 }
@@ -540,6 +580,7 @@ void s2s_destroy(s2s_handle* h) {
     if (h->ws_sigma) (void)hipFree(h->ws_sigma);
     if (h->ws_counts) (void)hipFree(h->ws_counts);
     if (h->ws_offs) (void)hipFree(h->ws_offs);
+    if (h->d_diag) (void)hipFree(h->d_diag);
     delete h;
 }
 
@@ -563,6 +604,7 @@ int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const
         D.emb_out = dbg->emb_out; D.enc_out = dbg->enc_out; D.sigma = dbg->sigma; D.conc = dbg->conc;
         D.rate = dbg->rate; D.g = dbg->g; D.y_scaled = dbg->y_scaled; D.z01 = dbg->z01;
     }
+    D.diag = h->d_diag;
     const int nb = S2S_T_ENC + h->cfg.seq_kmer - 1;
     for (int64_t s = 0; s < B; s += h->tile) {
         const int n = (int)((B - s < h->tile) ? (B - s) : h->tile);
@@ -650,6 +692,15 @@ int s2s_get_kernel_ms(s2s_handle* h, double* ms_total, int64_t* launches, int64_
     if (ms_total) *ms_total = tot;
     if (launches) *launches = nl;
     if (chunks) *chunks = nc;
+    return S2S_OK;
+}
+
+int s2s_diag_read(s2s_handle* h, uint64_t* out16) {
+    if (!h || !out16) return S2S_ERR_ARG;
+    if (!h->d_diag) return fail(h, S2S_ERR_ARG, "not a diagnostic (-DS2S_DIAG) build");
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(out16, h->d_diag, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemset(h->d_diag, 0, 16 * sizeof(uint64_t)));
     return S2S_OK;
 }
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Build the -DS2S_DIAG library, run the bench workload once and print where decoder waves spend cycles."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib = os.path.join(ROOT, "seq2squiggle_amd", "lib", "libs2s_hip_diag.so")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DS2S_DIAG",
+                "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
+os.environ["S2S_HIP_LIB"] = lib
+import numpy as np, torch
+import seq2squiggle_amd as S
+from seq2squiggle_amd import _lib
+sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
+eng = S.Engine(sd, cfg)
+rng = np.random.default_rng(0)
+reads = ["".join(rng.choice(list("ACGT"), 5000)) for _ in range(105)]
+bases, nv, _ = S.encode_reads(reads, 9)
+b, n = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda()
+out = (C.c_uint64 * 16)()
+for it in range(2):
+    eng.predict_chunks(b, n, S.PredictParams(seed=1))
+    _lib.lib().s2s_diag_read(eng._h, out)
+v = list(out)
+names = {0: "entry barrier wait", 1: "K/V GEMM + LDS store", 2: "barrier 2 wait", 3: "attention (Q, S, softmax, PV, fc)",
+         4: "LN1", 5: "FFN", 6: "LN2", 8: "prologue (LR gather)", 9: "epilogue", 15: "blocks total"}
+tot = sum(v[i] for i in (0, 1, 2, 3, 4, 5, 6, 8, 9))
+nw = bases.shape[0] * 8
+for i in sorted(names):
+    print(f"{names[i]:40s} {v[i] / nw:12.0f} cycles/wave  {100 * v[i] / tot:5.1f} %")
+print(f"total {tot / nw:.0f} cycles per wave per chunk")
