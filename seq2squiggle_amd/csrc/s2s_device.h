@@ -58,13 +58,31 @@ struct DebugDev {
 #define DIAG_STAMP(slot)
 #endif
 
+#ifndef S2S_ABL
+#define S2S_ABL 0      // timing-only ablations (tools/ablate.py); results are garbage when non-zero
+#endif
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ float sum_g(float v) { v += xor16(v); v += xor32(v); return v; }   // over the 4 lane groups
-__device__ __forceinline__ float max_g(float v) { v = fmaxf(v, xor16(v)); v = fmaxf(v, xor32(v)); return v; }
+// Reductions over the 4 lane groups (lanes c, c+16, c+32, c+48) with the gfx950 row/half swaps
+// (v_permlane16_swap: odd rows of a <-> even rows of b; v_permlane32_swap: upper half of a <-> lower
+// half of b): pure VALU, no LDS round trip.
+__device__ __forceinline__ float sum_g(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned w = __float_as_uint(v);
+    auto t = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float max_g(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const unsigned w = __float_as_uint(v);
+    auto t = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: the draw for (chunk, position, kind) never
@@ -238,6 +256,7 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
         mm_unit<NQ>(av, fb, X);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+            if (S2S_ABL & 8) { asm volatile("" ::"v"(ak[q]), "v"(av[q])); continue; }
             const int key = 16 * (qt0 + q) + c;
             // rows of the packed Wk tile are permuted so that registers {0,1} are head 2p
             // (d = 2g, 2g+1) and registers {2,3} head 2p+1: exactly the float2 the S MFMA reads
@@ -259,7 +278,7 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
     DIAG_STAMP(1);
-    __syncthreads();                       // K/V of every wave visible
+    if (!(S2S_ABL & 4)) __syncthreads();   // K/V of every wave visible
     DIAG_STAMP(2);
 
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
@@ -275,68 +294,98 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
         f32x4 op[NQ];                      // O^T of the pair: rows 0-7 head 2p, rows 8-15 head 2p+1
 #pragma unroll
         for (int q = 0; q < NQ; ++q) op[q] = f32x4{0, 0, 0, 0};
+        // Keys are processed in NH passes of HK tiles with a running max (flash-style).  Per pass the K and
+        // V^T operand fragments are read from LDS once, up front, and serve all NQ time tiles; o0/o1 are
+        // two accumulation chains so that no MFMA waits on the one issued just before it.
+        constexpr int NH = (NKT >= 16) ? 2 : 1;
+        constexpr int HK = NKT / NH;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const f32x2* kp = Kl + ((2 * p + hh) * 4 + g) * G::KPS + c;
             const float* vp = ((c >> 3) == hh) ? (Vl + (p * 16 + c) * G::RS + 4 * g) : (Zl + 4 * g);
+            f32x4 o0[NQ], o1[NQ];
+            float m[NQ], l[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { o0[q] = f32x4{0, 0, 0, 0}; o1[q] = f32x4{0, 0, 0, 0}; m[q] = -__builtin_inff(); l[q] = 0.0f; }
+#pragma unroll
+            for (int h2 = 0; h2 < NH; ++h2) {
+                f32x2 ka[HK];
+                f32x4 va[HK];
+#pragma unroll
+                for (int kt = 0; kt < HK; ++kt) ka[kt] = (S2S_ABL & 2) ? f32x2{qp[0][0], qp[0][1]} : kp[16 * (h2 * HK + kt)];
+#pragma unroll
+                for (int kt = 0; kt < HK; ++kt)
+                    va[kt] = (S2S_ABL & 2) ? qp[0] : *reinterpret_cast<const f32x4*>(vp + 16 * (h2 * HK + kt));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float q0 = qp[q][2 * hh], q1 = qp[q][2 * hh + 1];
+                    f32x4 s[HK];
+                    if (HK == 1) {
+                        s[0] = MFMA4(ka[0][0], q0, (f32x4{0, 0, 0, 0}));
+                        s[0] = MFMA4(ka[0][1], q1, s[0]);
+                    } else {
+#pragma unroll
+                        for (int kt = 0; kt + 1 < HK; kt += 2) {   // two tiles interleaved: no back-to-back dependent MFMA
+                            s[kt] = MFMA4(ka[kt][0], q0, (f32x4{0, 0, 0, 0}));
+                            s[kt + 1] = MFMA4(ka[kt + 1][0], q0, (f32x4{0, 0, 0, 0}));
+                            s[kt] = MFMA4(ka[kt][1], q1, s[kt]);
+                            s[kt + 1] = MFMA4(ka[kt + 1][1], q1, s[kt + 1]);
+                        }
+                    }
+                    if (TV < 16 * NKT && h2 == NH - 1) {   // phantom keys -> -inf (only the last key tile has any)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * (NKT - 1) + 4 * g + r >= TV) s[HK - 1][r] = -__builtin_inff();
+                    }
+                    float mh = s[0][0];
+                    if (!(S2S_ABL & 1)) {
+#pragma unroll
+                        for (int kt = 0; kt < HK; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[kt][r]);
+                    }
+                    const float mn = (S2S_ABL & 1) ? mh : fmaxf(m[q], max_g(mh));
+                    if (h2 > 0 && !(S2S_ABL & 1)) {        // rescale what was accumulated against the old max
+                        const float alpha = __builtin_amdgcn_exp2f((m[q] - mn) * c1);
+                        l[q] *= alpha;
+                        o0[q] *= alpha; o1[q] *= alpha;
+                    }
+                    m[q] = mn;
+                    const float mc = -mn * c1;
+                    float lh = 1.0f;
+                    if (!(S2S_ABL & 1)) {
+                        lh = 0.0f;
+#pragma unroll
+                        for (int kt = 0; kt < HK; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, mc));
+                                s[kt][r] = e;
+                                lh += e;
+                            }
+                    }
+                    l[q] += lh;
+                    if (hh == 1 && q == NQ - 1 && h2 == NH - 1) {
+                        // the pair's last P.V covers the latency of the next two weight units:
+                        // Wfc columns of pair p, then Wq rows of pair p+1 (after the last pair: W1 unit 0)
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_unit(fb, ws); load_unit(fa, ws + 1024); ws += 2048;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < HK; ++kt) {
+                        o0[q] = MFMA4(va[kt][0], s[kt][0], o0[q]);
+                        o1[q] = MFMA4(va[kt][1], s[kt][1], o1[q]);
+                        o0[q] = MFMA4(va[kt][2], s[kt][2], o0[q]);
+                        o1[q] = MFMA4(va[kt][3], s[kt][3], o1[q]);
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                f32x4 s[NKT];
-                const float q0 = qp[q][2 * hh], q1 = qp[q][2 * hh + 1];
-                if (NKT == 1) {
-                    const f32x2 a = kp[0];
-                    s[0] = MFMA4(a[0], q0, (f32x4{0, 0, 0, 0}));
-                    s[0] = MFMA4(a[1], q1, s[0]);
-                } else {
-#pragma unroll
-                    for (int kt = 0; kt + 1 < NKT; kt += 2) {      // two tiles interleaved: no back-to-back dependent MFMA
-                        const f32x2 a0 = kp[16 * kt], a1 = kp[16 * kt + 16];
-                        s[kt] = MFMA4(a0[0], q0, (f32x4{0, 0, 0, 0}));
-                        s[kt + 1] = MFMA4(a1[0], q0, (f32x4{0, 0, 0, 0}));
-                        s[kt] = MFMA4(a0[1], q1, s[kt]);
-                        s[kt + 1] = MFMA4(a1[1], q1, s[kt + 1]);
-                    }
-                }
-                if (TV < 16 * NKT) {       // phantom keys -> -inf (only the last key tile has any)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * (NKT - 1) + 4 * g + r >= TV) s[NKT - 1][r] = -__builtin_inff();
-                }
-                float m = s[0][0];
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-                m = max_g(m);
-                const float mc = -m * c1;
-                float l = 0.0f;
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, mc));
-                        s[kt][r] = e;
-                        l += e;
-                    }
-                l = sum_g(l);
-                if (hh == 1 && q == NQ - 1) {
-                    // the pair's last P.V (64 MFMAs) covers the latency of the next two weight units:
-                    // Wfc columns of pair p, then Wq rows of pair p+1 (after the last pair: W1 unit 0)
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_unit(fb, ws); load_unit(fa, ws + 1024); ws += 2048;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                f32x4 o0 = f32x4{0, 0, 0, 0}, o1 = f32x4{0, 0, 0, 0};
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 16 * kt);
-                    o0 = MFMA4(a[0], s[kt][0], o0);
-                    o1 = MFMA4(a[1], s[kt][1], o1);
-                    o0 = MFMA4(a[2], s[kt][2], o0);
-                    o1 = MFMA4(a[3], s[kt][3], o1);
-                }
-                const float inv = 1.0f / l;
-                op[q] += (o0 + o1) * inv;  // the other head's rows are exact zeros
+                const float inv = 1.0f / sum_g(l[q]);
+                op[q] += (o0[q] + o1[q]) * inv;  // the other head's rows are exact zeros
             }
         }
         // fc: acc += Wfc[:, 16p : 16p+16] * O_pair^T   (unit = the 4 m-tiles of k-tile p)
@@ -348,7 +397,7 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
                 for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMA4(fb[mt][r], op[q][r], acc[q][mt]);
     }
     DIAG_STAMP(3);
-    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+    if (!(S2S_ABL & 16)) layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
     DIAG_STAMP(4);
 
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
@@ -390,6 +439,6 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
         }
     }
     DIAG_STAMP(5);
-    layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+    if (!(S2S_ABL & 16)) layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
     DIAG_STAMP(6);
 }

@@ -1,0 +1,18 @@
+#!/usr/bin/env python
+"""Timing-only ablations of the decoder kernel (-DS2S_ABL=mask builds; outputs are garbage).
+bit0 no softmax VALU, bit1 no LDS operand reads, bit2 no barriers, bit3 no K/V LDS stores, bit4 no LayerNorm."""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+masks = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 31]
+for m in masks:
+    lib = os.path.join(ROOT, "seq2squiggle_amd", "lib", f"libs2s_hip_abl{m}.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f"-DS2S_ABL={m}",
+                    "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
+    env = dict(os.environ, S2S_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "420",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True)
+    try:
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        print(f"ABL={m:3d}  chunks/s {d['chunks_per_sec']:10.0f}  decoder frac-of-peak {d['roofline']['frac']:.3f}", flush=True)
+    except Exception as e:
+        print("ABL", m, "failed", e, r.stderr[-500:])
