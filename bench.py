@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3"],
+                    help="decoder arithmetic: f32-input MFMA, or split-f16 (3 f16 MFMA products, fp32 accumulate)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,7 +83,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
-    eng = S.Engine(sd, cfg, device=local)
+    eng = S.Engine(sd, cfg, device=local, mode=a.mode)
     dev = eng.device
     reads = make_reads(a.reads, 1234 + rank)               # every rank: its own shard of the read set
     bases, nv, first = S.encode_reads(reads, cfg["seq_kmer"])

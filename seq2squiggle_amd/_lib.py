@@ -10,7 +10,8 @@ _lib = None
 class S2SConfig(C.Structure):
     _fields_ = [("seq_kmer", C.c_int32), ("max_dna_len", C.c_int32), ("max_signal_len", C.c_int32),
                 ("dmodel", C.c_int32), ("dff", C.c_int32), ("n_heads", C.c_int32), ("encoder_layers", C.c_int32),
-                ("decoder_layers", C.c_int32), ("pre_layers", C.c_int32), ("scaling_max_value", C.c_float)]
+                ("decoder_layers", C.c_int32), ("pre_layers", C.c_int32), ("scaling_max_value", C.c_float),
+                ("compute_mode", C.c_int32)]
 
 
 class S2SParams(C.Structure):

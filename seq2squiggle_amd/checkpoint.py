@@ -53,13 +53,18 @@ def state_dict_to_blob(sd: Dict[str, torch.Tensor], cfg: dict) -> np.ndarray:
     return np.concatenate([sd[n].detach().float().cpu().numpy().ravel() for n in blob_names(cfg)]).astype(np.float32)
 
 
-def config_to_c(cfg: dict) -> S2SConfig:
+MODES = {"f32": 0, "f16x3": 1}
+
+
+def config_to_c(cfg: dict, mode: str = "f32") -> S2SConfig:
     if cfg["encoder_heads"] != cfg["decoder_heads"]:
         raise ValueError("encoder_heads != decoder_heads is not supported")
+    if mode not in MODES:
+        raise ValueError(f"mode must be one of {sorted(MODES)}")
     if cfg.get("allowed_chars", "_ACGT") != "_ACGT":
         raise ValueError("allowed_chars must be '_ACGT'")
     return S2SConfig(seq_kmer=int(cfg["seq_kmer"]), max_dna_len=int(cfg["max_dna_len"]),
                      max_signal_len=int(cfg["max_signal_len"]), dmodel=int(cfg["dmodel"]), dff=int(cfg["dff"]),
                      n_heads=int(cfg["encoder_heads"]), encoder_layers=int(cfg["encoder_layers"]),
                      decoder_layers=int(cfg["decoder_layers"]), pre_layers=int(cfg["pre_layers"]),
-                     scaling_max_value=float(cfg["scaling_max_value"]))
+                     scaling_max_value=float(cfg["scaling_max_value"]), compute_mode=MODES[mode])

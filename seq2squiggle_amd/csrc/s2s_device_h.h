@@ -1,0 +1,329 @@
+// s2s_device_h.h -- the FFT block on the f16 matrix cores with fp32-class accuracy.
+//
+// The f32-input MFMA (s2s_device.h) runs on the same FMA lanes as the vector ALU: softmax VALU
+// work and matrix work serialise and the block tops out near 57 % of the f32 matrix rate.  Here
+// every product a*b is evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with a = a_hi + a_lo split
+// into two f16 values (22 significant bits), on v_mfma_f32_16x16x32_f16 with fp32 accumulation:
+// products of two f16 are exact in fp32, so the only errors are the 2^-22 representation error of
+// each operand and the dropped lo*lo term.  Measured end to end (tests/test_gpu_parity.py) the
+// signal stays within the same 1e-4 pA MAE bound as the f32 path.  The matrix cores run beside the
+// vector ALU, which is left with the softmax, the hi/lo splits and the LayerNorms.
+//
+// Data layout is the same "transposed" scheme as s2s_device.h: activations are B operands, taken
+// straight from accumulator registers.  For the K = 32 MFMA the B operand of k-block kb is built
+// from the two 16-row accumulator tiles 2kb and 2kb+1 (element j of lane (g, c): tile 2kb + (j>>2),
+// register j&3, i.e. feature 32kb + 16(j>>2) + 4g + (j&3)); the host packs the weights' A fragments
+// in that same k order.
+#pragma once
+#include "s2s_device.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+struct HL { h8 hi, lo; };
+
+__device__ __forceinline__ h8 as_h8(const f32x4 v) { return __builtin_bit_cast(h8, v); }
+
+// x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significant bits
+__device__ __forceinline__ HL split8(const f32x4 t0, const f32x4 t1) {
+    HL o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 h0 = (_Float16)t0[j], h1 = (_Float16)t1[j];
+        o.hi[j] = h0; o.hi[4 + j] = h1;
+        o.lo[j] = (_Float16)(t0[j] - (float)h0);
+        o.lo[4 + j] = (_Float16)(t1[j] - (float)h1);
+    }
+    return o;
+}
+__device__ __forceinline__ void split4(const f32x4 t, h4& hi, h4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)t[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(t[j] - (float)h);
+    }
+}
+
+// LDS of the f16 block (NKT = 16 key tiles): K [head][hi|lo][key][8 d] halves, V^T [head][16 rows:
+// 0-7 hi d, 8-15 lo d][VS keys] halves, and a per-wave scratch for the Q^T operand re-layout.
+template <int NQ, int WAVES> struct AttnLdsH {
+    static constexpr int K_BYTES = 8 * 2 * 256 * 8 * 2;
+    static constexpr int VS = 264;                        // halves per V row: (VS/2) % 64 == 4 -> conflict-free b64 reads
+    static constexpr int V_BYTES = 8 * 16 * VS * 2;
+    static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
+    static constexpr int BYTES = K_BYTES + V_BYTES + WAVES * Q_WAVE_BYTES;
+};
+
+// acc[q] += W_unit * x[q]: one 16-row m-tile, K = 64 as two k-blocks, three products each.
+// Unit layout (4 KiB): [kb0 hi][kb0 lo][kb1 hi][kb1 lo], 16 B per lane each.
+template <int NQ>
+__device__ __forceinline__ void mm_unit_h(f32x4 (&acc)[NQ], const f32x4 (&f)[4], const HL (&x)[NQ][2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const h8 wh = as_h8(f[2 * kb]), wl = as_h8(f[2 * kb + 1]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wh, x[q][kb].hi, acc[q]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wh, x[q][kb].lo, acc[q]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wl, x[q][kb].hi, acc[q]);
+    }
+}
+
+// One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h; T = 250 only.
+template <int NQ, int WAVES, int TV>
+__device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
+                                            char* __restrict__ lds, int qt0, int wave, int lane,
+                                            unsigned long long* diag_buf = nullptr) {
+    using G = AttnLdsH<NQ, WAVES>;
+    constexpr int NKT = 16, NH = 2, HK = NKT / NH, HB = HK / 2;
+    const int g = lane >> 4, c = lane & 15;
+    DIAG_DECL;
+    _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
+    _Float16* __restrict__ Vl = reinterpret_cast<_Float16*>(lds + G::K_BYTES);
+    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + wave * G::Q_WAVE_BYTES);
+    const float* ws = W + L.stream_h + lane * 4;
+    f32x4 fa[4], fb[4];
+    load_unit(fa, ws); ws += 1024;                    // Wk, pair 0
+
+    HL xb[NQ][2];                                     // block input as B operands
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1]); xb[q][1] = split8(X[q][2], X[q][3]); }
+
+    __syncthreads();                                  // every wave is done reading the previous block's K/V
+    DIAG_STAMP(0);
+    // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        load_unit(fb, ws); ws += 1024;                // Wv, pair p
+        const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g), bv = ldg4(W + L.bv + 16 * p + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 ak[NQ], av[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { ak[q] = bk; av[q] = bv; }
+        mm_unit_h<NQ>(ak, fa, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_unit(fa, ws); ws += 1024;                // Wk, pair p+1 (after the last pair: Wq, pair 0)
+        __builtin_amdgcn_sched_barrier(0);
+        mm_unit_h<NQ>(av, fb, xb);
+        const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // accumulator rows 4g..4g+3 = head, d0..d0+3
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int key = 16 * (qt0 + q) + c;
+            h4 hi, lo;
+            split4(ak[q], hi, lo);
+            *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * 256 + key) * 8 + d0) = hi;
+            *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * 256 + key) * 8 + d0) = lo;
+            split4(av[q], hi, lo);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Vl[(head * 16 + d0 + r) * G::VS + key] = hi[r];
+                Vl[(head * 16 + 8 + d0 + r) * G::VS + key] = lo[r];
+            }
+        }
+    }
+    // ---- fc accumulator starts as bias + residual (layers.py:85-86)
+    f32x4 acc[NQ][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = ldg4(W + L.bfc + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
+    }
+    DIAG_STAMP(1);
+    __syncthreads();                                  // K/V of every wave visible
+    DIAG_STAMP(2);
+
+    const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
+    h8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+#pragma unroll 1
+    for (int u = 0; u < 2; ++u) {                     // two head pairs per iteration = one K = 32 block of fc
+        f32x4 opair[2][NQ];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int p = 2 * u + pp;
+            // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
+            if (pp == 0) { load_unit(fb, ws); ws += 1024; } else { load_unit(fa, ws); ws += 1024; }
+            const f32x4 bq = ldg4(W + L.bq_nat + 16 * p + 4 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 qa[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) qa[q] = bq;
+            if (pp == 0) mm_unit_h<NQ>(qa, fa, xb); else mm_unit_h<NQ>(qa, fb, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            // Q^T rows live 4 per lane group; the S MFMA wants all 8 d of a head in every lane
+            // ([Q_hi | Q_lo | Q_hi | Q_lo] over the lane groups): re-layout through the wave's scratch
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                h4 hi, lo;
+                split4(qa[q], hi, lo);
+                *reinterpret_cast<h4*>(Ql + (((q * 2 + 0) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = hi;
+                *reinterpret_cast<h4*>(Ql + (((q * 2 + 1) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = lo;
+            }
+            f32x4 ohead[2][NQ];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int head = 2 * p + hh;
+                h8 qb[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    qb[q] = *reinterpret_cast<const h8*>(Ql + (((q * 2 + (g & 1)) * 2 + hh) * 16 + c) * 8);
+                const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * 256 + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
+                const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
+                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
+                float m[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
+                    lH[q] = f32x4{0, 0, 0, 0}; lL[q] = f32x4{0, 0, 0, 0};
+                    m[q] = -__builtin_inff();
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < NH; ++h2) {
+                    h8 ka[HK], va[HB];
+#pragma unroll
+                    for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
+#pragma unroll
+                    for (int kb = 0; kb < HB; ++kb) {
+                        const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (2 * (h2 * HB + kb)));
+                        const h4 v1 = *reinterpret_cast<const h4*>(vp + 16 * (2 * (h2 * HB + kb) + 1));
+                        va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        f32x4 s[HK];
+#pragma unroll
+                        for (int kt = 0; kt < HK; ++kt) s[kt] = MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0}));
+                        if (TV < 16 * NKT && h2 == NH - 1) {   // phantom keys -> -inf (only the last key tile has any)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * (NKT - 1) + 4 * g + r >= TV) s[HK - 1][r] = -__builtin_inff();
+                        }
+                        float mh = s[0][0];
+#pragma unroll
+                        for (int kt = 0; kt < HK; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[kt][r]);
+                        const float mn = fmaxf(m[q], max_g(mh));
+                        if (h2 > 0) {                      // rescale what was accumulated against the old max
+                            const float alpha = __builtin_amdgcn_exp2f((m[q] - mn) * c1);
+                            oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
+                        }
+                        m[q] = mn;
+                        const float mc = -mn * c1;
+#pragma unroll
+                        for (int kt = 0; kt < HK; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, mc));
+#pragma unroll
+                        for (int kb = 0; kb < HB; ++kb) {
+                            const HL P = split8(s[2 * kb], s[2 * kb + 1]);
+                            oH[q] = MFMAH(va[kb], P.hi, oH[q]);      // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                            oL[q] = MFMAH(va[kb], P.lo, oL[q]);      // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                            lH[q] = MFMAH(ones, P.hi, lH[q]);        // every row: sum of the P actually used
+                            lL[q] = MFMAH(ones, P.lo, lL[q]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 t = oH[q] + oL[q];
+                    const float inv = 1.0f / (lH[q][0] + lL[q][0]);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {            // O[d] = row d + row 8+d: the other half-wave's value
+                        const unsigned uu = __float_as_uint(t[r]);
+                        auto sw = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+                        o[r] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * inv;
+                    }
+                    ohead[hh][q] = o;                      // lanes g and g^2 both hold d = 4(g&1) + r
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) opair[pp][q] = (g < 2) ? ohead[0][q] : ohead[1][q];   // pair tile: row 4g+r
+        }
+        // ---- fc, k-block u (the 4 heads just finished): acc += Wfc[:, 32u : 32u+32] * O^T
+        HL ob[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q]);
+        load_unit(fb, ws); ws += 1024;                // Wfc(u), m-tiles 2-3
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {        // unit = [mt a hi][mt a lo][mt b hi][mt b lo]
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const h8 wh = as_h8(half == 0 ? fa[2 * mm] : fb[2 * mm]);
+                const h8 wl = as_h8(half == 0 ? fa[2 * mm + 1] : fb[2 * mm + 1]);
+                const int mt = 2 * half + mm;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].hi, acc[q][mt]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].lo, acc[q][mt]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wl, ob[q].hi, acc[q][mt]);
+            }
+            if (half == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_unit(fa, ws); ws += 1024;        // next iteration's Wq (after the last: W1 unit 0)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    DIAG_STAMP(3);
+    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+    DIAG_STAMP(4);
+
+    // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
+    HL x1b[NQ][2];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1]); x1b[q][1] = split8(acc[q][2], acc[q][3]); }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;      // X = bias + residual accumulator
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < 4; ++hc) {
+        f32x4 hid[NQ][4];
+        f32x4 b1[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {              // W1 units: rows 64hc + 16mt ..
+            f32x4 t[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[q] = b1[mt];
+            if (mt & 1) { load_unit(fa, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fb, x1b); }
+            else        { load_unit(fb, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fa, x1b); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
+        }
+        HL hb[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1]); hb[q][1] = split8(hid[q][2], hid[q][3]); }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
+            f32x4 t[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
+            if (mt & 1) { load_unit(fa, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fb, hb); }
+            else        { load_unit(fb, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fa, hb); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
+        }
+    }
+    DIAG_STAMP(5);
+    layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+    DIAG_STAMP(6);
+}

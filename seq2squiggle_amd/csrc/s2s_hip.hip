@@ -9,6 +9,7 @@
 //                        wave), output projection, x165, Philox noise, clamp -> signal[250]
 // plus s2s_export_* for the per-read zero-strip / int16 conversion.
 #include "s2s_device.h"
+#include "s2s_device_h.h"
 #include "../../include/s2s_hip.h"
 
 #include <cstdio>
@@ -155,12 +156,16 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
 #define DEC_WAVES 8
 #define DEC_NQ 2            // 16-column time tiles per wave: 8 waves x 2 x 16 = 256 >= 250
 #define DEC_NKT 16
+static constexpr int DEC_LDS_F32 = AttnLds<DEC_NKT>::BYTES;
+static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES>::BYTES;
 
+template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h)
 __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
     const float* __restrict__ ws_sigma, const int* __restrict__ dur, long long first_chunk, ParamsDev P,
     const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float* lds = reinterpret_cast<float*>(lds_raw);
     const int b = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -199,7 +204,10 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     }
     DIAG_STAMP(8);
 #pragma unroll 1
-    for (int l = 0; l < M.dec_layers; ++l) fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
+    for (int l = 0; l < M.dec_layers; ++l) {
+        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, dbg.diag);
+        else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
+    }
 
     // ---- out_linear + ReLU (modules.py:140-141), x165 (model.py:221), noise where != 0
     //      (model.py:224-238), clamp (model.py:240)
@@ -380,6 +388,7 @@ const char* check_cfg(const s2s_config* c) {
     if (c->encoder_layers < 1 || c->encoder_layers > S2S_MAX_LAYERS) return "encoder_layers must be 1..4";
     if (c->decoder_layers < 1 || c->decoder_layers > S2S_MAX_LAYERS) return "decoder_layers must be 1..4";
     if (c->pre_layers < 0 || c->pre_layers > S2S_MAX_LAYERS) return "pre_layers must be 0..4";
+    if (c->compute_mode != S2S_MODE_F32 && c->compute_mode != S2S_MODE_F16X3) return "compute_mode must be S2S_MODE_F32 or S2S_MODE_F16X3";
     return nullptr;
 }
 
@@ -455,6 +464,40 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     }
     st.resize(st.size() + 1024, 0.0f);       // the block's last prefetch reads one unit past its stream
     L.stream = A.put(st.data(), st.size());
+    // the same units for the split-f16 block: per (m-tile, k-block of 32) a hi and a lo fragment of
+    // 64 lanes x 8 halves; lane (g, i), element j: W[16mt + i][kbase + 16(j>>2) + 4g + (j&3)]
+    std::vector<_Float16> sh;
+    auto frag_h = [&](const float* Wm, int K, int mt, int kbase, bool lo) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, i = lane & 15;
+            for (int j = 0; j < 8; ++j) {
+                const float w = Wm[(size_t)(16 * mt + i) * K + kbase + 16 * (j >> 2) + 4 * g + (j & 3)];
+                const _Float16 hi = (_Float16)w;
+                sh.push_back(lo ? (_Float16)(w - (float)hi) : hi);
+            }
+        }
+    };
+    auto unit_h = [&](const float* Wm, int K, int mt, int kbase) {      // [kb0 hi][kb0 lo][kb1 hi][kb1 lo]
+        for (int kb = 0; kb < 2; ++kb) { frag_h(Wm, K, mt, kbase + 32 * kb, false); frag_h(Wm, K, mt, kbase + 32 * kb, true); }
+    };
+    for (int p_ = 0; p_ < 4; ++p_) { unit_h(wk, 64, p_, 0); unit_h(wv, 64, p_, 0); }
+    for (int u = 0; u < 2; ++u) {
+        unit_h(wq, 64, 2 * u, 0);
+        unit_h(wq, 64, 2 * u + 1, 0);
+        for (int mt = 0; mt < 4; ++mt) { frag_h(wfc, 64, mt, 32 * u, false); frag_h(wfc, 64, mt, 32 * u, true); }
+    }
+    for (int hc = 0; hc < 4; ++hc) {
+        for (int mt = 0; mt < 4; ++mt) unit_h(w1, 64, 4 * hc + mt, 0);
+        for (int mt = 0; mt < 4; ++mt) unit_h(w2, 256, mt, 64 * hc);
+    }
+    sh.resize(sh.size() + 2048, (_Float16)0.0f);
+    {
+        std::vector<float> raw(sh.size() / 2);
+        std::memcpy(raw.data(), sh.data(), sh.size() * sizeof(_Float16));
+        L.stream_h = A.put(raw.data(), raw.size());
+    }
+    L.bq_nat = A.put(bq, 64);
+    L.bk_nat = A.put(bk, 64);
     L.bq = A.put_bias_perm(bq, 64);
     L.bk = A.put_bias_perm(bk, 64);
     L.bv = A.put(bv, 64);
@@ -560,9 +603,12 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     h->tile = 32768;
     if ((e = hipMalloc(&h->ws_enc, (size_t)h->tile * 16 * 64 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(ws_enc)");
     if ((e = hipMalloc(&h->ws_sigma, (size_t)h->tile * 16 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(ws_sigma)");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  AttnLds<DEC_NKT>::BYTES)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute(decoder LDS)");
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 DEC_LDS_H)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute(decoder LDS, f16 block)");
 #ifdef S2S_DIAG
     if ((e = hipMalloc(&h->d_diag, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
     if ((e = hipMemset(h->d_diag, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
@@ -617,10 +663,16 @@ int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const
             HIP_TRY(h, hipEventCreate(&ev.b));
             HIP_TRY(h, hipEventRecord(ev.a, stream));
         }
-        hipLaunchKernelGGL(s2s_decoder_kernel, dim3(n), dim3(DEC_WAVES * 64), AttnLds<DEC_NKT>::BYTES, stream, h->model,
-                           h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, (long long)(first_global_chunk + s), P,
-                           inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
-                           (long long)s);
+        if (h->cfg.compute_mode == S2S_MODE_F16X3)
+            hipLaunchKernelGGL(s2s_decoder_kernel<1>, dim3(n), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
+                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, (long long)(first_global_chunk + s),
+                               P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
+                               (long long)s);
+        else
+            hipLaunchKernelGGL(s2s_decoder_kernel<0>, dim3(n), dim3(DEC_WAVES * 64), AttnLds<DEC_NKT>::BYTES, stream, h->model,
+                               h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, (long long)(first_global_chunk + s), P,
+                               inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
+                               (long long)s);
         if (h->profiling) {
             HIP_TRY(h, hipEventRecord(ev.b, stream));
             ev.chunks = n;

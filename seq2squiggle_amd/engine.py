@@ -42,7 +42,8 @@ def _ptr(t: Optional[torch.Tensor]):
 class Engine:
     """Weights resident on one GPU + the predict / export entry points."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], config: dict, device: Optional[int] = None):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: dict, device: Optional[int] = None,
+                 mode: str = "f32"):
         self._h = None
         L = _lib.lib()                       # raises when the HIP extension is missing
         if not torch.cuda.is_available():
@@ -51,7 +52,8 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         self.config = dict(config)
         self.k = int(config["seq_kmer"])
-        ccfg = config_to_c(config)
+        self.mode = mode
+        ccfg = config_to_c(config, mode)
         blob = np.ascontiguousarray(state_dict_to_blob(state_dict, config))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -62,9 +64,9 @@ class Engine:
         self._h = h
 
     @classmethod
-    def from_checkpoint(cls, path: str, device: Optional[int] = None) -> "Engine":
+    def from_checkpoint(cls, path: str, device: Optional[int] = None, mode: str = "f32") -> "Engine":
         sd, cfg = load_checkpoint(path)
-        return cls(sd, cfg, device)
+        return cls(sd, cfg, device, mode)
 
     def close(self):
         if self._h is not None:

@@ -25,11 +25,12 @@ def P(**kw):
     return base
 
 
-@pytest.fixture(scope="module", params=["k9", "k6"])
+@pytest.fixture(scope="module", params=[("k9", "f32"), ("k6", "f32"), ("k9", "f16x3"), ("k6", "f16x3")],
+                ids=lambda p: f"{p[0]}-{p[1]}")
 def case(request):
-    tag = request.param
+    tag, mode = request.param
     sd, cfg = load_ckpt(tag)
-    eng = S.Engine(sd, cfg)
+    eng = S.Engine(sd, cfg, mode=mode)
     g = load_npz(f"stages_{tag}.npz")
     bases, nv = chunker.codes_to_bases(g["codes"])
     dev = eng.device
