@@ -20,31 +20,72 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+#ifndef S2S_ALWAYS_RESCALE
+#define S2S_ALWAYS_RESCALE 0
+#endif
 #define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 struct HL { h8 hi, lo; };
 
 __device__ __forceinline__ h8 as_h8(const f32x4 v) { return __builtin_bit_cast(h8, v); }
 
-// x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significant bits
+// x = hi + lo with hi = f16(x) (round to nearest), lo = f16(x - hi): 22 significant bits.  Three VALU
+// instructions per pair of values: one packed convert, then v_fma_mix{lo,hi}_f16 computes
+// x * 1.0 - f32(hi) from the fp32 value and the f16 half in a single rounding straight to f16.
+// (hipcc's own lowering of the C expression takes five.)  A consumer MFMA must not be the very next
+// instruction after these (VALU write -> MFMA operand needs 2 wait states the compiler cannot see
+// through inline asm): every call site puts other work or an s_nop in between.
+__device__ __forceinline__ void split2(const float a, const float b, unsigned& hi, unsigned& lo) {
+#ifdef S2S_SPLIT_C
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    hi = __builtin_bit_cast(unsigned, (h2v{ha, hb}));
+    lo = __builtin_bit_cast(unsigned, (h2v{(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)}));
+    return;
+#endif
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(hi));
+}
+// p = exp2(s) for four scores and its hi/lo f16 split in one statement: the exponentials are
+// transcendental ops, whose results a following VALU instruction may only read after one wait state
+// (gfx940+ trans forwarding hazard) -- inside the statement the ordering guarantees that, which the
+// compiler cannot do for operands of inline asm.  p itself is not needed afterwards (the row sum
+// comes out of the MFMA with a ones operand).
+__device__ __forceinline__ void exp_split4(const f32x4 s, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+    float t0, t1, t2, t3;
+    asm("v_exp_f32 %4, %8\n\t"
+        "v_exp_f32 %5, %9\n\t"
+        "v_exp_f32 %6, %10\n\t"
+        "v_exp_f32 %7, %11\n\t"
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
+}
+typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+typedef unsigned uv2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ HL split8(const f32x4 t0, const f32x4 t1) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(t0[0], t0[1], h0, l0);
+    split2(t0[2], t0[3], h1, l1);
+    split2(t1[0], t1[1], h2, l2);
+    split2(t1[2], t1[3], h3, l3);
     HL o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 h0 = (_Float16)t0[j], h1 = (_Float16)t1[j];
-        o.hi[j] = h0; o.hi[4 + j] = h1;
-        o.lo[j] = (_Float16)(t0[j] - (float)h0);
-        o.lo[4 + j] = (_Float16)(t1[j] - (float)h1);
-    }
+    o.hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2, h3}));
+    o.lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
     return o;
 }
 __device__ __forceinline__ void split4(const f32x4 t, h4& hi, h4& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 h = (_Float16)t[j];
-        hi[j] = h;
-        lo[j] = (_Float16)(t[j] - (float)h);
-    }
+    unsigned h0, h1, l0, l1;
+    split2(t[0], t[1], h0, l0);
+    split2(t[2], t[3], h1, l1);
+    hi = __builtin_bit_cast(h4, (uv2{h0, h1}));
+    lo = __builtin_bit_cast(h4, (uv2{l0, l1}));
 }
 
 // LDS of the f16 block (NKT = 16 key tiles): K [head][hi|lo][key][8 d] halves, V^T [head][16 rows:
@@ -79,7 +120,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                                             char* __restrict__ lds, int qt0, int wave, int lane,
                                             unsigned long long* diag_buf = nullptr) {
     using G = AttnLdsH<NQ, WAVES>;
-    constexpr int NKT = 16, NH = 2, HK = NKT / NH, HB = HK / 2;
+    constexpr int NKT = 16, NH = 4, HK = NKT / NH, HB = HK / 2;   // 4 passes of 64 keys
+    constexpr float THR = 8.0f;                                  // deferred-max threshold (log2 units)
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
@@ -92,6 +134,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     HL xb[NQ][2];                                     // block input as B operands
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1]); xb[q][1] = split8(X[q][2], X[q][3]); }
+    asm volatile("s_nop 1");
 
     __syncthreads();                                  // every wave is done reading the previous block's K/V
     DIAG_STAMP(0);
@@ -101,9 +144,11 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         load_unit(fb, ws); ws += 1024;                // Wv, pair p
         const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g), bv = ldg4(W + L.bv + 16 * p + 4 * g);
         __builtin_amdgcn_sched_barrier(0);
+        // bias is added after the GEMM: the inline-asm split below must read results of compiler-visible
+        // VALU instructions, never an MFMA accumulator directly (MFMA -> VALU read needs wait states)
         f32x4 ak[NQ], av[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { ak[q] = bk; av[q] = bv; }
+        for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
         mm_unit_h<NQ>(ak, fa, xb);
         __builtin_amdgcn_sched_barrier(0);
         load_unit(fa, ws); ws += 1024;                // Wk, pair p+1 (after the last pair: Wq, pair 0)
@@ -114,10 +159,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) {
             const int key = 16 * (qt0 + q) + c;
             h4 hi, lo;
-            split4(ak[q], hi, lo);
+            split4(ak[q] + bk, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * 256 + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * 256 + key) * 8 + d0) = lo;
-            split4(av[q], hi, lo);
+            split4(av[q] + bv, hi, lo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 Vl[(head * 16 + d0 + r) * G::VS + key] = hi[r];
@@ -153,7 +198,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             __builtin_amdgcn_sched_barrier(0);
             f32x4 qa[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) qa[q] = bq;
+            for (int q = 0; q < NQ; ++q) qa[q] = f32x4{0, 0, 0, 0};
             if (pp == 0) mm_unit_h<NQ>(qa, fa, xb); else mm_unit_h<NQ>(qa, fb, xb);
             __builtin_amdgcn_sched_barrier(0);
             // Q^T rows live 4 per lane group; the S MFMA wants all 8 d of a head in every lane
@@ -161,7 +206,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 h4 hi, lo;
-                split4(qa[q], hi, lo);
+                split4((qa[q] + bq) * c1, hi, lo);               // scores come out in log2 units
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 0) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = hi;
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 1) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
@@ -175,14 +220,20 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     qb[q] = *reinterpret_cast<const h8*>(Ql + (((q * 2 + (g & 1)) * 2 + hh) * 16 + c) * 8);
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * 256 + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
-                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
+                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ], negm[NQ];
                 float m[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
                     lH[q] = f32x4{0, 0, 0, 0}; lL[q] = f32x4{0, 0, 0, 0};
-                    m[q] = -__builtin_inff();
+                    negm[q] = f32x4{0, 0, 0, 0};
+                    m[q] = 0.0f;
                 }
+                // Online softmax over NH passes.  Pass 0 subtracts its own column max.  Later passes get
+                // "score - running max" straight out of the MFMA (the accumulator starts at -m), and the
+                // running max is only raised -- with the accumulators rescaled -- when some column of the
+                // wave exceeds it by more than THR (p <= 2^THR otherwise): softmax is shift-invariant, so
+                // this changes rounding only.
 #pragma unroll
                 for (int h2 = 0; h2 < NH; ++h2) {
                     h8 ka[HK], va[HB];
@@ -199,7 +250,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     for (int q = 0; q < NQ; ++q) {
                         f32x4 s[HK];
 #pragma unroll
-                        for (int kt = 0; kt < HK; ++kt) s[kt] = MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0}));
+                        for (int kt = 0; kt < HK; ++kt)
+                            s[kt] = (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
                         if (TV < 16 * NKT && h2 == NH - 1) {   // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -210,24 +262,38 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         for (int kt = 0; kt < HK; ++kt)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[kt][r]);
-                        const float mn = fmaxf(m[q], max_g(mh));
-                        if (h2 > 0) {                      // rescale what was accumulated against the old max
-                            const float alpha = __builtin_amdgcn_exp2f((m[q] - mn) * c1);
+                        const float gm = max_g(mh);
+                        if (h2 == 0) {
+                            m[q] = gm;
+                            negm[q] = f32x4{-gm, -gm, -gm, -gm};
+#pragma unroll
+                            for (int kt = 0; kt < HK; ++kt) s[kt] -= gm;
+                        } else if (S2S_ALWAYS_RESCALE || __any(gm > THR)) {          // rare: raise the running max, rescale what was summed
+                            const float delta = fmaxf(gm, 0.0f);
+                            const float alpha = __builtin_amdgcn_exp2f(-delta);
                             oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
+                            m[q] += delta;
+                            negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
+#pragma unroll
+                            for (int kt = 0; kt < HK; ++kt) s[kt] -= delta;
                         }
-                        m[q] = mn;
-                        const float mc = -mn * c1;
-#pragma unroll
-                        for (int kt = 0; kt < HK; ++kt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, mc));
+                        HL P[HB];
 #pragma unroll
                         for (int kb = 0; kb < HB; ++kb) {
-                            const HL P = split8(s[2 * kb], s[2 * kb + 1]);
-                            oH[q] = MFMAH(va[kb], P.hi, oH[q]);      // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                            oL[q] = MFMAH(va[kb], P.lo, oL[q]);      // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
-                            lH[q] = MFMAH(ones, P.hi, lH[q]);        // every row: sum of the P actually used
-                            lL[q] = MFMAH(ones, P.lo, lL[q]);
+                            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+                            exp_split4(s[2 * kb], h0, h1, l0, l1);
+                            exp_split4(s[2 * kb + 1], h2_, h3, l2, l3);
+                            P[kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
+                            P[kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 1");
+#pragma unroll
+                        for (int kb = 0; kb < HB; ++kb) {
+                            oH[q] = MFMAH(va[kb], P[kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                            oL[q] = MFMAH(va[kb], P[kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                            lH[q] = MFMAH(ones, P[kb].hi, lH[q]);    // every row: sum of the P actually used
+                            lL[q] = MFMAH(ones, P[kb].lo, lL[q]);
                         }
                     }
                 }
@@ -252,6 +318,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         HL ob[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q]);
+        asm volatile("s_nop 1");
         load_unit(fb, ws); ws += 1024;                // Wfc(u), m-tiles 2-3
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -283,6 +350,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     HL x1b[NQ][2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1]); x1b[q][1] = split8(acc[q][2], acc[q][3]); }
+    asm volatile("s_nop 1");
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
@@ -311,6 +379,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         HL hb[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1]); hb[q][1] = split8(hid[q][2], hid[q][3]); }
+        asm volatile("s_nop 1");
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
             f32x4 t[NQ];

@@ -11,7 +11,7 @@ import numpy as np, torch
 import seq2squiggle_amd as S
 from seq2squiggle_amd import _lib
 sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
-eng = S.Engine(sd, cfg)
+eng = S.Engine(sd, cfg, mode=(sys.argv[1] if len(sys.argv) > 1 else "f16x3"))
 rng = np.random.default_rng(0)
 reads = ["".join(rng.choice(list("ACGT"), 5000)) for _ in range(105)]
 bases, nv, _ = S.encode_reads(reads, 9)
