@@ -20,7 +20,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)

@@ -29,61 +29,49 @@ struct HL { h8 hi, lo; };
 
 __device__ __forceinline__ h8 as_h8(const f32x4 v) { return __builtin_bit_cast(h8, v); }
 
-// x = hi + lo with hi = f16(x) (round to nearest), lo = f16(x - hi): 22 significant bits.  Three VALU
-// instructions per pair of values: one packed convert, then v_fma_mix{lo,hi}_f16 computes
-// x * 1.0 - f32(hi) from the fp32 value and the f16 half in a single rounding straight to f16.
-// (hipcc's own lowering of the C expression takes five.)  A consumer MFMA must not be the very next
-// instruction after these (VALU write -> MFMA operand needs 2 wait states the compiler cannot see
-// through inline asm): every call site puts other work or an s_nop in between.
-__device__ __forceinline__ void split2(const float a, const float b, unsigned& hi, unsigned& lo) {
-#ifdef S2S_SPLIT_C
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    hi = __builtin_bit_cast(unsigned, (h2v{ha, hb}));
-    lo = __builtin_bit_cast(unsigned, (h2v{(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)}));
-    return;
-#endif
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(hi));
+// x = hi + lo with hi = f16(x) (round to nearest), lo = f16(x - hi): 22 significant bits, in three
+// VALU instructions per pair of values: v_cvt_pk_f16_f32, then v_fma_mix{lo,hi}_f16 computes
+// x * 1.0 - f32(hi) from the fp32 value and the f16 half with a single rounding straight to f16.
+// Written in C so that every instruction stays visible to the compiler's hazard recogniser (MFMA <->
+// VALU wait states, trans forwarding): `one` is an opaque 1.0f (otherwise fma(x, 1, c) folds to an add
+// and the mix form is lost), the empty asm makes the packed hi opaque so its halves are reused through
+// op_sel instead of being converted again, and the file is built with -fno-slp-vectorize (the SLP
+// vectoriser would turn the two fmas into v_pk_fma_f32 plus separate conversions: five instructions).
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(const float a, const float b, const float one, unsigned& hi, unsigned& lo) {
+    unsigned hb = __builtin_bit_cast(unsigned, (h2v{(_Float16)a, (_Float16)b}));
+    asm("" : "+v"(hb));
+    const h2v h = __builtin_bit_cast(h2v, hb);
+    const h2v l = {(_Float16)__builtin_fmaf(a, one, -(float)h[0]), (_Float16)__builtin_fmaf(b, one, -(float)h[1])};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, l);
 }
-// p = exp2(s) for four scores and its hi/lo f16 split in one statement: the exponentials are
-// transcendental ops, whose results a following VALU instruction may only read after one wait state
-// (gfx940+ trans forwarding hazard) -- inside the statement the ordering guarantees that, which the
-// compiler cannot do for operands of inline asm.  p itself is not needed afterwards (the row sum
-// comes out of the MFMA with a ones operand).
-__device__ __forceinline__ void exp_split4(const f32x4 s, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
-    float t0, t1, t2, t3;
-    asm("v_exp_f32 %4, %8\n\t"
-        "v_exp_f32 %5, %9\n\t"
-        "v_exp_f32 %6, %10\n\t"
-        "v_exp_f32 %7, %11\n\t"
-        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
-        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
+// p = exp2(s) for four scores, split.  p itself is not needed afterwards (the row sum comes out of
+// the MFMA with a ones operand).
+__device__ __forceinline__ void exp_split4(const f32x4 s, const float one, unsigned& h0, unsigned& h1, unsigned& l0,
+                                           unsigned& l1) {
+    const float e0 = __builtin_amdgcn_exp2f(s[0]), e1 = __builtin_amdgcn_exp2f(s[1]);
+    const float e2 = __builtin_amdgcn_exp2f(s[2]), e3 = __builtin_amdgcn_exp2f(s[3]);
+    split2(e0, e1, one, h0, l0);
+    split2(e2, e3, one, h1, l1);
 }
 typedef unsigned uv4 __attribute__((ext_vector_type(4)));
 typedef unsigned uv2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ HL split8(const f32x4 t0, const f32x4 t1) {
+__device__ __forceinline__ HL split8(const f32x4 t0, const f32x4 t1, const float one) {
     unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2(t0[0], t0[1], h0, l0);
-    split2(t0[2], t0[3], h1, l1);
-    split2(t1[0], t1[1], h2, l2);
-    split2(t1[2], t1[3], h3, l3);
+    split2(t0[0], t0[1], one, h0, l0);
+    split2(t0[2], t0[3], one, h1, l1);
+    split2(t1[0], t1[1], one, h2, l2);
+    split2(t1[2], t1[3], one, h3, l3);
     HL o;
     o.hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2, h3}));
     o.lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
     return o;
 }
-__device__ __forceinline__ void split4(const f32x4 t, h4& hi, h4& lo) {
+__device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h4& lo) {
     unsigned h0, h1, l0, l1;
-    split2(t[0], t[1], h0, l0);
-    split2(t[2], t[3], h1, l1);
+    split2(t[0], t[1], one, h0, l0);
+    split2(t[2], t[3], one, h1, l1);
     hi = __builtin_bit_cast(h4, (uv2{h0, h1}));
     lo = __builtin_bit_cast(h4, (uv2{l0, l1}));
 }
@@ -117,7 +105,7 @@ __device__ __forceinline__ void mm_unit_h(f32x4 (&acc)[NQ], const f32x4 (&f)[4],
 // One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h; T = 250 only.
 template <int NQ, int WAVES, int TV>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
-                                            char* __restrict__ lds, int qt0, int wave, int lane,
+                                            char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr) {
     using G = AttnLdsH<NQ, WAVES>;
     constexpr int NKT = 16, NH = 4, HK = NKT / NH, HB = HK / 2;   // 4 passes of 64 keys
@@ -133,8 +121,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 
     HL xb[NQ][2];                                     // block input as B operands
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1]); xb[q][1] = split8(X[q][2], X[q][3]); }
-    asm volatile("s_nop 1");
+    for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
 
     __syncthreads();                                  // every wave is done reading the previous block's K/V
     DIAG_STAMP(0);
@@ -159,10 +146,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) {
             const int key = 16 * (qt0 + q) + c;
             h4 hi, lo;
-            split4(ak[q] + bk, hi, lo);
+            split4(ak[q] + bk, one, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * 256 + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * 256 + key) * 8 + d0) = lo;
-            split4(av[q] + bv, hi, lo);
+            split4(av[q] + bv, one, hi, lo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 Vl[(head * 16 + d0 + r) * G::VS + key] = hi[r];
@@ -206,7 +193,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 h4 hi, lo;
-                split4((qa[q] + bq) * c1, hi, lo);               // scores come out in log2 units
+                split4((qa[q] + bq) * c1, one, hi, lo);               // scores come out in log2 units
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 0) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = hi;
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 1) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
@@ -246,54 +233,68 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
+                    // beside the other's exponentials inside the same wave
+                    f32x4 s[NQ][HK];
+                    float gm[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        f32x4 s[HK];
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt)
-                            s[kt] = (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+                            s[q][kt] = (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+                    bool raise = false;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
                         if (TV < 16 * NKT && h2 == NH - 1) {   // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (16 * (NKT - 1) + 4 * g + r >= TV) s[HK - 1][r] = -__builtin_inff();
+                                if (16 * (NKT - 1) + 4 * g + r >= TV) s[q][HK - 1][r] = -__builtin_inff();
                         }
-                        float mh = s[0][0];
+                        float mh = s[q][0][0];
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[kt][r]);
-                        const float gm = max_g(mh);
-                        if (h2 == 0) {
-                            m[q] = gm;
-                            negm[q] = f32x4{-gm, -gm, -gm, -gm};
+                            for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[q][kt][r]);
+                        gm[q] = max_g(mh);
+                        raise = raise || (gm[q] > THR);
+                    }
+                    if (h2 == 0) {
 #pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) s[kt] -= gm;
-                        } else if (S2S_ALWAYS_RESCALE || __any(gm > THR)) {          // rare: raise the running max, rescale what was summed
-                            const float delta = fmaxf(gm, 0.0f);
+                        for (int q = 0; q < NQ; ++q) {
+                            m[q] = gm[q];
+                            negm[q] = f32x4{-gm[q], -gm[q], -gm[q], -gm[q]};
+#pragma unroll
+                            for (int kt = 0; kt < HK; ++kt) s[q][kt] -= gm[q];
+                        }
+                    } else if (S2S_ALWAYS_RESCALE || __any(raise)) {   // rare: raise the running max, rescale the sums
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const float delta = fmaxf(gm[q], 0.0f);
                             const float alpha = __builtin_amdgcn_exp2f(-delta);
                             oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
                             m[q] += delta;
                             negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
 #pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) s[kt] -= delta;
+                            for (int kt = 0; kt < HK; ++kt) s[q][kt] -= delta;
                         }
-                        HL P[HB];
+                    }
+                    HL P[NQ][HB];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                         for (int kb = 0; kb < HB; ++kb) {
                             unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
-                            exp_split4(s[2 * kb], h0, h1, l0, l1);
-                            exp_split4(s[2 * kb + 1], h2_, h3, l2, l3);
-                            P[kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
-                            P[kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
+                            exp_split4(s[q][2 * kb], one, h0, h1, l0, l1);
+                            exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
+                            P[q][kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
+                            P[q][kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("s_nop 1");
 #pragma unroll
                         for (int kb = 0; kb < HB; ++kb) {
-                            oH[q] = MFMAH(va[kb], P[kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                            oL[q] = MFMAH(va[kb], P[kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
-                            lH[q] = MFMAH(ones, P[kb].hi, lH[q]);    // every row: sum of the P actually used
-                            lL[q] = MFMAH(ones, P[kb].lo, lL[q]);
+                            oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                            oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                            lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
+                            lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
                         }
                     }
                 }
@@ -317,9 +318,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         // ---- fc, k-block u (the 4 heads just finished): acc += Wfc[:, 32u : 32u+32] * O^T
         HL ob[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q]);
-        asm volatile("s_nop 1");
-        load_unit(fb, ws); ws += 1024;                // Wfc(u), m-tiles 2-3
+        for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q], one);
+            load_unit(fb, ws); ws += 1024;                // Wfc(u), m-tiles 2-3
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {        // unit = [mt a hi][mt a lo][mt b hi][mt b lo]
@@ -349,8 +349,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
     HL x1b[NQ][2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1]); x1b[q][1] = split8(acc[q][2], acc[q][3]); }
-    asm volatile("s_nop 1");
+    for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1], one); x1b[q][1] = split8(acc[q][2], acc[q][3], one); }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
@@ -378,9 +377,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         }
         HL hb[NQ][2];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1]); hb[q][1] = split8(hid[q][2], hid[q][3]); }
-        asm volatile("s_nop 1");
-#pragma unroll
+        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1], one); hb[q][1] = split8(hid[q][2], hid[q][3], one); }
+    #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
             f32x4 t[NQ];
 #pragma unroll

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int qt0 = DEC_NQ * wave;
+    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
+    asm volatile("" : "+s"(one));
 
     // ---- length regulator (modules.py:344-392) as a gather: row t copies encoder row
     //      i(t) = #{j : cum[j] <= t}; rows past cum[15] are zero; crop at 250; then + position_enc
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     DIAG_STAMP(8);
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
-        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, dbg.diag);
+        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
         else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
     }
 

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 masks = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 31]
 for m in masks:
     lib = os.path.join(ROOT, "seq2squiggle_amd", "lib", f"libs2s_hip_abl{m}.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f"-DS2S_ABL={m}",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", f"-DS2S_ABL={m}",
                     "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
     env = dict(os.environ, S2S_HIP_LIB=lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "420",
