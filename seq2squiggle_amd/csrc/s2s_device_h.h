@@ -50,8 +50,12 @@ __device__ __forceinline__ void split2(const float a, const float b, const float
 // the MFMA with a ones operand).
 __device__ __forceinline__ void exp_split4(const f32x4 s, const float one, unsigned& h0, unsigned& h1, unsigned& l0,
                                            unsigned& l1) {
-    const float e0 = __builtin_amdgcn_exp2f(s[0]), e1 = __builtin_amdgcn_exp2f(s[1]);
-    const float e2 = __builtin_amdgcn_exp2f(s[2]), e3 = __builtin_amdgcn_exp2f(s[3]);
+    const float e0 = (S2S_ABL & 1) ? s[0] : __builtin_amdgcn_exp2f(s[0]), e1 = (S2S_ABL & 1) ? s[1] : __builtin_amdgcn_exp2f(s[1]);
+    const float e2 = (S2S_ABL & 1) ? s[2] : __builtin_amdgcn_exp2f(s[2]), e3 = (S2S_ABL & 1) ? s[3] : __builtin_amdgcn_exp2f(s[3]);
+    if (S2S_ABL & 2) {      // timing only: no split arithmetic
+        h0 = __float_as_uint(e0); l0 = __float_as_uint(e1); h1 = __float_as_uint(e2); l1 = __float_as_uint(e3);
+        return;
+    }
     split2(e0, e1, one, h0, l0);
     split2(e2, e3, one, h1, l1);
 }
@@ -123,7 +127,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
 
-    __syncthreads();                                  // every wave is done reading the previous block's K/V
+    if (!(S2S_ABL & 4)) __syncthreads();              // every wave is done reading the previous block's K/V
     DIAG_STAMP(0);
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
 #pragma unroll 1
@@ -166,7 +170,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
     DIAG_STAMP(1);
-    __syncthreads();                                  // K/V of every wave visible
+    if (!(S2S_ABL & 4)) __syncthreads();              // K/V of every wave visible
     DIAG_STAMP(2);
 
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
@@ -222,7 +226,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 // wave exceeds it by more than THR (p <= 2^THR otherwise): softmax is shift-invariant, so
                 // this changes rounding only.
 #pragma unroll
-                for (int h2 = 0; h2 < NH; ++h2) {
+                for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
                     h8 ka[HK], va[HB];
 #pragma unroll
                     for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
@@ -236,12 +240,14 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
                     // beside the other's exponentials inside the same wave
                     f32x4 s[NQ][HK];
-                    float gm[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt)
                             s[q][kt] = (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+                    // per-lane partial maxima; the cross-lane reduction is only needed in pass 0 and on the
+                    // (rare) raise path -- the raise test itself is a wave-wide vote on the partial maxima
+                    float mh[NQ];
                     bool raise = false;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
@@ -250,26 +256,28 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                             for (int r = 0; r < 4; ++r)
                                 if (16 * (NKT - 1) + 4 * g + r >= TV) s[q][HK - 1][r] = -__builtin_inff();
                         }
-                        float mh = s[q][0][0];
+                        mh[q] = s[q][0][0];
+                        if (!(S2S_ABL & 32)) {
 #pragma unroll
-                        for (int kt = 0; kt < HK; ++kt)
+                            for (int kt = 0; kt < HK; ++kt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[q][kt][r]);
-                        gm[q] = max_g(mh);
-                        raise = raise || (gm[q] > THR);
+                                for (int r = 0; r < 4; ++r) mh[q] = fmaxf(mh[q], s[q][kt][r]);
+                        }
+                        raise = raise || (mh[q] > THR);
                     }
                     if (h2 == 0) {
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) {
-                            m[q] = gm[q];
-                            negm[q] = f32x4{-gm[q], -gm[q], -gm[q], -gm[q]};
+                            const float gm = (S2S_ABL & 32) ? mh[q] : max_g(mh[q]);
+                            m[q] = gm;
+                            negm[q] = f32x4{-gm, -gm, -gm, -gm};
 #pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) s[q][kt] -= gm[q];
+                            for (int kt = 0; kt < HK; ++kt) s[q][kt] -= gm;
                         }
-                    } else if (S2S_ALWAYS_RESCALE || __any(raise)) {   // rare: raise the running max, rescale the sums
+                    } else if (S2S_ALWAYS_RESCALE || (!(S2S_ABL & 32) && __any(raise))) {   // rare: raise the running max
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) {
-                            const float delta = fmaxf(gm[q], 0.0f);
+                            const float delta = fmaxf(max_g(mh[q]), 0.0f);
                             const float alpha = __builtin_amdgcn_exp2f(-delta);
                             oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
                             m[q] += delta;
@@ -293,8 +301,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         for (int kb = 0; kb < HB; ++kb) {
                             oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
                             oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                            if (!(S2S_ABL & 64)) {
                             lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
                             lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
+                            }
                         }
                     }
                 }
@@ -357,7 +367,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;      // X = bias + residual accumulator
     }
 #pragma unroll 1
-    for (int hc = 0; hc < 4; ++hc) {
+    for (int hc = 0; hc < ((S2S_ABL & 128) ? 0 : 4); ++hc) {
         f32x4 hid[NQ][4];
         f32x4 b1[4];
 #pragma unroll

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Timing-only ablations of the decoder kernel (-DS2S_ABL=mask builds; outputs are garbage).
-bit0 no softmax VALU, bit1 no LDS operand reads, bit2 no barriers, bit3 no K/V LDS stores, bit4 no LayerNorm."""
+f32 block: bit0 no softmax VALU, bit1 no LDS operand reads, bit2 no barriers, bit3 no K/V LDS stores, bit4 no LayerNorm.
+f16 block: 1 no exp, 2 no split, 4 no barriers, 32 no max/branch, 64 no row-sum MFMAs, 128 no FFN, 256 one key pass of four."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 masks = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 31]
@@ -10,7 +11,7 @@ for m in masks:
                     "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
     env = dict(os.environ, S2S_HIP_LIB=lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "420",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True)
+                        "--no-cpu-baseline", "--mode", os.environ.get("S2S_ABL_MODE", "f16x3")], env=env, capture_output=True, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
         print(f"ABL={m:3d}  chunks/s {d['chunks_per_sec']:10.0f}  decoder frac-of-peak {d['roofline']['frac']:.3f}", flush=True)
