@@ -27,6 +27,10 @@ import seq2squiggle_amd as S  # noqa: E402
 FLOP_PER_CHUNK = 85_083_392            # 2 x 42,541,696 MAC, k = 9
 FLOP_PER_CHUNK_DECODER = 2 * 40_592_000  # decoder-side share (the dominant kernel), SURVEY.md section 2.2
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA
+# f16x3 evaluates every algorithmic product as three f16 MFMA products (hi*hi + hi*lo + lo*hi), so
+# the matrix-core ceiling for ALGORITHMIC flops is a third of the dense f16 peak.
+PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0}
 READ_LEN, CHUNKS_PER_READ = 5000, 312
 
 
@@ -127,15 +131,18 @@ def main():
             "metric": "signal samples/sec at 5 kb reads (padded [chunks x 250] samples the predict path emits)",
             "value": chunks_s * 250, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.reads} synthetic reads x {READ_LEN} nt per GPU ({B} chunks/step/GPU), "
+            "dtype": "f32" if a.mode == "f32" else "f16x3 (two-term f16 split operands, fp32 accumulate; fp32-class accuracy)",
+            "data": "synthetic",
+            "config": {"mode": a.mode, "workload": f"{a.reads} synthetic reads x {READ_LEN} nt per GPU ({B} chunks/step/GPU), "
                                    "default noise+duration samplers, synthetic k=9 checkpoint",
                        "chunks_per_step_per_gpu": B, "profile": "dna-r10-prom", "seed": 42},
             "reads_per_sec": chunks_s / CHUNKS_PER_READ, "chunks_per_sec": chunks_s,
             "emitted_samples_per_sec": emitted * world / (el / a.steps),
             "roofline": {"bound": "mfma", "kernel": "s2s_decoder_kernel", "achieved": tflops,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (tflops / PEAK_F32_MFMA_TFLOPS) if tflops else None, "traffic": None,
+                         "peak": PEAK[a.mode], "unit": "TFLOP/s",
+                         "frac": (tflops / PEAK[a.mode]) if tflops else None, "traffic": None,
+                         "peak_note": ("f32-input MFMA peak" if a.mode == "f32" else
+                                       "dense f16 MFMA peak / 3 products per algorithmic product; achieved counts algorithmic flops"),
                          "flop_per_chunk": FLOP_PER_CHUNK_DECODER,
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "launches": dec_launches, "chunks_per_launch": dec_chunks / dec_launches if dec_launches else None},
