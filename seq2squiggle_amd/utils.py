@@ -1,0 +1,293 @@
+"""Host-side helpers of the predict path: profiles, config patching, FASTA/FASTQ input, read
+sampling, seeds, logging.
+
+Mirrors the public names of the reference's utils.py so that `inference_run` reads the same:
+get_profile (utils.py:129-215), update_profile (218-243), update_config (245-263), read_fasta
+(290-308), draw_{gamma,beta,expon}_dis (311-331), sampling (415-479),
+sample_reads_from_reference (495-582), preprocess_genome (608-638), get_reads (641-671),
+set_seeds (722-741), setup_logging (687-719).  Training-only helpers (plots, parameter tables)
+are out of scope.
+"""
+import gzip
+import logging
+import os
+import random
+import sys
+from typing import Dict, Generator, Iterable, List, Tuple
+from uuid import uuid4
+
+import numpy as np
+import scipy.stats as st
+
+logger = logging.getLogger("seq2squiggle")
+
+_PROFILES = {
+    # name: digitisation, sample_rate, bps, range, offset_mean, offset_std, median_before_mean, median_before_std
+    "dna-r10-min": (8192, 5000, 400, 1536.598389, 13.380569389019, 16.311471649012, 202.15407438804, 13.406139241768),
+    "dna-r10-prom": (2048, 5000, 400, 281.345551, -127.5655735, 19.377283387665, 189.87607393756, 15.788097978713),
+    "dna-r9-min": (8192, 4000, 450, 1443.030273, 13.7222605, 10.25279688, 200.815801, 20.48933762),
+    "dna-r9-prom": (2048, 4000, 450, 748.5801, -237.4102, 14.1575, 214.2890337, 18.0127916),
+    "rna-004-min": (8192, 4000, 130, 1437.976685, 12.47686423863, 10.442126577137, 205.08496731088, 8.6671292866233),
+    "rna-004-prom": (2048, 4000, 130, 299.432068, -259.421128, 16.010841823643, 189.87607393756, 15.788097978713),
+}
+_PROFILE_KEYS = ("digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std", "median_before_mean",
+                 "median_before_std")
+
+
+def get_profile(profile: str) -> Dict[str, float]:
+    """Profile dict for the writers (reference: utils.py:129-215).  Unknown name -> logged error, None."""
+    if profile in _PROFILES:
+        return dict(zip(_PROFILE_KEYS, _PROFILES[profile]))
+    logger.error(f"Incorrect value for profile: {profile}")
+    return None
+
+
+def update_profile(profile_dict: dict, **kwargs) -> dict:
+    """Non-None overrides replace profile entries (utils.py:218-243)."""
+    for key, value in kwargs.items():
+        if value is not None and key in profile_dict:
+            profile_dict[key] = value
+        elif key not in profile_dict:
+            logger.warning(f"Warning: {key} is not a valid key in the profile")
+    return profile_dict
+
+
+def update_config(profile_name: str, config: dict) -> dict:
+    """seq_kmer follows the chemistry (utils.py:245-263)."""
+    if profile_name.startswith("dna-r10") or profile_name.startswith("rna-004"):
+        config["seq_kmer"] = 9
+    elif profile_name.startswith("dna-r9"):
+        config["seq_kmer"] = 6
+    else:
+        raise ValueError(f"Unsupported profile name: {profile_name}. Expected 'dna-r10' or 'dna-r9' prefix.")
+    return config
+
+
+# --------------------------------------------------------------------------------------- FASTA / FASTQ
+def _open_text(path):
+    path = str(path)
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
+
+
+def read_fasta(path: str, rna: bool = False) -> Generator[Tuple[str, str], None, None]:
+    """(sequence, name) for every FASTA or FASTQ record (reference: pysam.FastxFile, utils.py:290-308).
+    name = header up to the first whitespace, as pysam's `entry.name`; multi-line FASTA is joined."""
+    with _open_text(path) as fh:
+        name, seq, mode = None, [], None
+        it = iter(fh)
+        for line in it:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            if mode is None:
+                mode = "fq" if line[0] == "@" else "fa"
+            if mode == "fa":
+                if line[0] == ">":
+                    if name is not None:
+                        yield "".join(seq), name
+                    parts = line[1:].split()
+                    name, seq = (parts[0] if parts else ""), []
+                elif name is not None:
+                    seq.append(line.strip())
+            else:
+                if line[0] != "@":
+                    raise ValueError(f"{path}: malformed FASTQ record header: {line[:40]!r}")
+                parts = line[1:].split()
+                rname = parts[0] if parts else ""
+                s = next(it).rstrip("\r\n")
+                plus = next(it)
+                next(it)
+                if not plus.startswith("+"):
+                    raise ValueError(f"{path}: malformed FASTQ record {rname}")
+                yield s, rname
+        if mode == "fa" and name is not None:
+            yield "".join(seq), name
+
+
+# --------------------------------------------------------------------------------------- read sampling
+def draw_gamma_dis(mean, seed, total_len):
+    sample = st.gamma.rvs(6.3693711, 0.53834893, size=1, random_state=seed)
+    sample = int(sample[0] * mean / 4.39)
+    return np.clip(sample, 1, total_len)
+
+
+def draw_beta_dis(mean, seed, total_len):
+    sample = st.beta.rvs(1.778, 7.892, 316.758, 34191.257, size=1, random_state=seed)
+    sample = (sample[0] * mean / 6615.0).astype(int)
+    return np.clip(sample, 1, total_len)
+
+
+def draw_expon_dis(mean, seed, total_len):
+    sample = st.expon.rvs(loc=213.98910256668592, scale=6972.5319847131141, size=1, random_state=seed)
+    sample = (sample[0] * mean / 7106.0).astype(int)
+    return np.clip(sample, 1, total_len)
+
+
+_DISTR = {"beta": draw_beta_dis, "gamma": draw_gamma_dis, "expon": draw_expon_dis}
+_COMPLEMENT = str.maketrans("ATCG", "TAGC")
+
+
+def get_genome_and_position(genome_lengths, random_position):
+    if random_position >= sum(genome_lengths):
+        raise ValueError("Random position exceeds the total length of genomes")
+    cumulative = 0
+    for i, length in enumerate(genome_lengths):
+        cumulative += length
+        if random_position < cumulative:
+            return i, random_position - (cumulative - length)
+
+
+def read_check(read, read_length, read_i, profile, min_read_len=30):
+    """utils.py:381-400: DNA reads must have the full drawn length (end-of-contig rejection), be at least
+    min_read_len long and carry at most 10 % N."""
+    if profile.startswith("dna") and len(read) != read_length:
+        return False
+    if len(read) < min_read_len:
+        return False
+    if read.count("N") > 0.1 * read_length:
+        return False
+    return True
+
+
+def N_to_ACTG(read):
+    return "".join(random.choice("ACGT") if base == "N" else base for base in read)
+
+
+def reverse_complement(f):
+    return f.translate(_COMPLEMENT)[::-1]
+
+
+def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20):
+    """Sample reads from the reference (utils.py:415-479).  The order of draws from the global `random`
+    stream (start position, strand, N replacement) and the per-(read, retry) scipy seed
+    `seed + read_i * (max_retries + 1) + retries` are those of the reference, so a seed selects the same
+    read set."""
+    sampled_reads = []
+    total_genome_len = sum(genome_lens)
+    for read_i in range(num_seqs):
+        retries = 0
+        while retries < max_retries:
+            start_pos = random.randint(0, total_genome_len - 1)
+            genome_index, start_index = get_genome_and_position(genome_lens, start_pos)
+            genome = genome_seqs[genome_index]
+            unique_seed = seed + read_i * (max_retries + 1) + retries
+            read_length = int(_DISTR[distr](r, unique_seed, total_len)) if r > 0 else len(genome)
+            read = genome[start_index:start_index + read_length]
+            if profile.startswith("dna"):
+                read_strand = random.choice("+-")
+            elif profile.startswith("rna"):
+                read_strand = "+"
+            if read_check(read, read_length, read_i, profile, min_read_len):
+                if "N" in read:
+                    read = N_to_ACTG(read)
+                if read_strand == "-":
+                    read = reverse_complement(read)
+                sampled_reads.append(read)
+                break
+            retries += 1
+            if retries >= max_retries:
+                logger.debug(f"Failed to sample a valid read after {max_retries} retries for read {read_i}. Skipping this read.")
+    return sampled_reads
+
+
+def yield_reads(reads):
+    return ((read, str(uuid4())) for read in reads)
+
+
+def export_fasta(read_l, fasta):
+    file_name, _ = os.path.splitext(fasta)
+    out_file = f"{file_name}_reads.fasta"
+    with open(out_file, "w") as f:
+        for read in read_l:
+            f.write(f">{uuid4()}\n{read}\n")
+    return out_file
+
+
+def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta, seed, save=False, distr="expon",
+                                profile="dna-r10-min", min_read_len=30):
+    """utils.py:495-582 (same argument checks and messages)."""
+    if n <= 0 and c <= 0:
+        raise ValueError("You need to specify the coverage c or the number of reads n")
+    if n != -1 and c != -1:
+        raise ValueError("You can only either specify the coverage c or the number of reads, but not both")
+    if r <= 0:
+        raise ValueError("You need to specify the read length r")
+    total_len = sum(len(seq) for seq in genome_seqs)
+    avg_genome_len = total_len / len(genome_seqs)
+    seq_num = n if n != -1 else round(c * total_len / r)
+    if r > avg_genome_len and profile.startswith("dna"):
+        logger.warning(f"Average reference sequence length ({avg_genome_len:.2f}) is smaller than the desired average "
+                       f"read length ({r}). Reads longer than their reference sequence are skipped; consider a smaller -r.")
+    read_list = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len)
+    total_l = sum(round(len(read) / config["max_dna_len"]) for read in read_list)
+    reads_fasta = export_fasta(read_list, fasta) if save else yield_reads(read_list)
+    return reads_fasta, total_l
+
+
+_NON_ACGT = bytes(ord("N") if chr(b) not in "ACGT" else b for b in range(256))
+
+
+def process_genome(genome_seq: str):
+    """upper-case, everything but ACGT -> N (utils.py:594-597)."""
+    g = genome_seq.upper().encode("latin-1").translate(_NON_ACGT).decode("latin-1")
+    return g, len(g)
+
+
+def preprocess_genome(fasta: str):
+    results = [process_genome(seq) for seq, _ in read_fasta(fasta)]
+    if not results:
+        raise ValueError(f"{fasta}: no sequences found")
+    seqs, lens = zip(*results)
+    return list(seqs), list(lens)
+
+
+def get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len, save=False):
+    """-> (iterable of (sequence, read_id), approximate chunk count)  (utils.py:641-671)."""
+    logger.info(f"{'Read' if read_input else 'Reference'} mode.")
+    is_rna = profile.startswith("rna")
+    if read_input:
+        if n <= 0:
+            total = sum(len(s) for s, _ in read_fasta(fasta, is_rna))
+            return read_fasta(fasta, is_rna), total
+        all_reads = list(read_fasta(fasta, is_rna))
+        rng = random.Random(seed)
+        sampled = [rng.choice(all_reads) for _ in range(n)]
+        effective = sum(round(len(seq) / config["max_dna_len"]) for seq, _ in sampled)
+        return ((seq, str(uuid4())) for seq, _ in sampled), effective
+    genome_seqs, genome_lens = preprocess_genome(fasta)
+    reads_fasta, total_l = sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, str(fasta), seed, save,
+                                                       distr, profile, min_read_len)
+    return (read_fasta(reads_fasta, is_rna), total_l) if save else (reads_fasta, total_l)
+
+
+# --------------------------------------------------------------------------------------- seeds / logging
+def set_seeds(seed: int) -> int:
+    """utils.py:722-741: seed 0 draws a fresh one; seeds python, numpy and torch.  Returns the seed used
+    (it also keys the device-side Philox generator)."""
+    import torch
+    if not seed:
+        seed = int.from_bytes(os.urandom(4), byteorder="big", signed=False)
+        logger.info(f"No seed provided. Generated random seed: {seed}")
+    logger.info(f"Setting all random seeds to {seed}")
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    np.random.seed(seed)
+    return seed
+
+
+def setup_logging(verbosity: str):
+    """Console handler on stderr, `{name} {levelname} {asctime}: {message}` (utils.py:687-719)."""
+    levels = {"debug": logging.DEBUG, "info": logging.INFO, "warning": logging.WARNING, "error": logging.ERROR}
+    logging.captureWarnings(True)
+    root = logging.getLogger()
+    root.setLevel(logging.DEBUG)
+    handler = logging.StreamHandler(sys.stderr)
+    handler.setLevel(levels[verbosity.lower()])
+    handler.setFormatter(logging.Formatter("{name} {levelname} {asctime}: {message}", style="{", datefmt="%H:%M:%S"))
+    root.addHandler(handler)
+    logging.getLogger("py.warnings").addHandler(handler)
+    for noisy in ("fsspec", "h5py", "torch", "urllib3"):
+        logging.getLogger(noisy).setLevel(logging.WARNING)

@@ -1,0 +1,91 @@
+"""Host front end: FASTA/FASTQ reader and the read sampler against read sets drawn by
+the reference's own `sampling` for the same seeds (tools/make_goldens.py: sampler_goldens)."""
+import gzip
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+from seq2squiggle_amd import utils as U
+from conftest import GOLDEN, load_npz
+
+LAMBDA = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+
+
+def test_read_fasta_and_fastq(tmp_path):
+    reads = list(U.read_fasta(os.path.join(GOLDEN, "example_test.fasta")))
+    assert len(reads) == 7 and reads[0][1] == "sequenceID-003-GAC-repeat" and len(reads[0][0]) == 96
+    fa = tmp_path / "m.fa"
+    fa.write_text(">r1 some description\nACGT\nacgtNN\n\n>r2\nTTTT\n")
+    assert list(U.read_fasta(str(fa))) == [("ACGTacgtNN", "r1"), ("TTTT", "r2")]
+    fq = tmp_path / "m.fastq.gz"
+    with gzip.open(fq, "wt") as f:
+        f.write("@q1 desc\nACGTAC\n+\nIIIIII\n@q2\nGG\n+q2\n@@\n")
+    assert list(U.read_fasta(str(fq))) == [("ACGTAC", "q1"), ("GG", "q2")]
+
+
+def test_process_genome():
+    g, n = U.process_genome("acgtRYn-ACGT")
+    assert g == "ACGTNNNNACGT" and n == 12
+
+
+CASES = ["lambda_expon_dna", "lambda_beta_dna", "lambda_gamma_rna", "two_contigs_cov"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sampler_matches_reference_read_sets(name):
+    g = load_npz("sampler.npz")
+    n, r, c, seed = (int(x) for x in g[name + "__args"])
+    distr, prof = (str(x) for x in g[name + "__distr_profile"])
+    lam = next(U.read_fasta(LAMBDA))[0]
+    if name == "two_contigs_cov":
+        seqs, lens = zip(*[U.process_genome(s) for s in (lam[:30000], str(g["two_contigs__seq1"]))])
+    else:
+        seqs, lens = zip(*[U.process_genome(lam)])
+    random.seed(seed)
+    cfg = {"max_dna_len": 16}
+    reads, total_l = U.sample_reads_from_reference(list(seqs), list(lens), n, r, c, cfg, "x.fasta", seed, False, distr, prof, 30)
+    reads = [rd for rd, _ in reads]
+    assert [len(x) for x in reads] == g[name + "__lens"].tolist()
+    assert [hashlib.sha1(x.encode()).hexdigest() for x in reads] == [str(x) for x in g[name + "__sha"]]
+    assert total_l == int(g[name + "__total_l"])
+
+
+def test_sampler_argument_errors():
+    cfg = {"max_dna_len": 16}
+    with pytest.raises(ValueError):
+        U.sample_reads_from_reference(["ACGT" * 100], [400], -1, 100, -1, cfg, "x", 1)
+    with pytest.raises(ValueError):
+        U.sample_reads_from_reference(["ACGT" * 100], [400], 5, 100, 3, cfg, "x", 1)
+    with pytest.raises(ValueError):
+        U.sample_reads_from_reference(["ACGT" * 100], [400], 5, 0, -1, cfg, "x", 1)
+
+
+def test_get_reads_read_mode(tmp_path):
+    cfg = {"max_dna_len": 16}
+    path = os.path.join(GOLDEN, "example_test.fasta")
+    reads, total = U.get_reads(path, True, -1, 1000, -1, cfg, "expon", 3, "dna-r10-prom", 30)
+    reads = list(reads)
+    assert len(reads) == 7 and total == sum(len(s) for s, _ in reads)
+    sampled, eff = U.get_reads(path, True, 5, 1000, -1, cfg, "expon", 3, "dna-r10-prom", 30)
+    sampled = list(sampled)
+    rng = random.Random(3)
+    expect = [rng.choice(reads)[0] for _ in range(5)]
+    assert [s for s, _ in sampled] == expect and eff == sum(round(len(s) / 16) for s in expect)
+
+
+def test_profiles_match_reference_table():
+    g = load_npz("profiles.npz")
+    for n in g["names"]:
+        p = U.get_profile(str(n))
+        assert [p[k] for k in ("digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std",
+                               "median_before_mean", "median_before_std")] == g[str(n) + "__profile"].tolist()
+    assert U.get_profile("nope") is None
+    cfg = U.update_config("dna-r9-min", {"seq_kmer": 9})
+    assert cfg["seq_kmer"] == 6 and U.update_config("rna-004-prom", {})["seq_kmer"] == 9
+    with pytest.raises(ValueError):
+        U.update_config("dna-r7", {})
+    p = U.update_profile(U.get_profile("dna-r10-prom"), sample_rate=4000, bps=None)
+    assert p["sample_rate"] == 4000 and p["bps"] == 400

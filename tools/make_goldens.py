@@ -381,8 +381,38 @@ def profile_goldens():
     np.savez_compressed(os.path.join(OUT, "profiles.npz"), **out)
 
 
+def sampler_goldens():
+    """Read sets drawn by the reference's own sampler for fixed seeds (utils.py:415-582)."""
+    import random, hashlib
+    genome = read_fasta(os.path.join(REF, "example/lamda_genome.fasta"))
+    seqs, lens = zip(*[RU.process_genome(s) for s, _ in genome])
+    # a two-contig reference with N runs and lower case, to cover the genome lookup and N handling
+    rng = np.random.default_rng(3)
+    c2 = "".join(rng.choice(list("ACGTN"), 20000, p=[.24, .24, .24, .24, .04])) + "acgtnnacgt" * 50
+    seqs2, lens2 = zip(*[RU.process_genome(s) for s in (genome[0][0][:30000], c2)])
+    out = {}
+    cases = [("lambda_expon_dna", seqs, lens, 25, 5000, -1, "expon", "dna-r10-prom", 42),
+             ("lambda_beta_dna", seqs, lens, 15, 3000, -1, "beta", "dna-r9-min", 7),
+             ("lambda_gamma_rna", seqs, lens, 15, 2000, -1, "gamma", "rna-004-prom", 11),
+             ("two_contigs_cov", seqs2, lens2, -1, 4000, 2, "expon", "dna-r10-min", 5)]
+    for name, gs, gl, n, r, c, distr, prof, seed in cases:
+        random.seed(seed)
+        reads, total_l = RU.sample_reads_from_reference(list(gs), list(gl), n, r, c, base_config(9), "x.fasta", seed,
+                                                        False, distr, prof, 30)
+        reads = [rd for rd, _ in reads]
+        out[name + "__lens"] = np.array([len(x) for x in reads])
+        out[name + "__sha"] = np.array([hashlib.sha1(x.encode()).hexdigest() for x in reads])
+        out[name + "__total_l"] = np.array(total_l)
+        out[name + "__args"] = np.array([n, r, c, seed])
+        out[name + "__distr_profile"] = np.array([distr, prof])
+        print(name, len(reads), "reads, mean len", np.mean([len(x) for x in reads]) if reads else 0)
+    out["two_contigs__seq1"] = np.array(c2)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    sampler_goldens()
     chunker_goldens()
     profile_goldens()
     reads = read_fasta(os.path.join(REF, "example/test.fasta"))
