@@ -1,0 +1,117 @@
+"""`seq2squiggle predict` command line (reference: seq2squiggle.py:43-84, 230-456, 458-599) on plain click.
+Same option names and defaults; the other commands of the reference (preprocess, train, sweep) are training
+and out of scope."""
+import logging
+import pathlib
+import sys
+
+import click
+import yaml
+
+from . import __version__
+
+logger = logging.getLogger("seq2squiggle")
+
+
+def set_config(config_path) -> dict:
+    """YAML config loader (seq2squiggle.py:640-657)."""
+    default_config_path = pathlib.Path(__file__).parent / "config.yaml"
+    path_to_use = default_config_path if config_path is None else config_path
+    try:
+        with open(path_to_use, "r") as f_in:
+            config = yaml.safe_load(f_in)
+    except FileNotFoundError:
+        logger.error(f"Configuration file not found: {path_to_use}")
+        raise
+    except yaml.YAMLError as exc:
+        logger.error(f"Error parsing YAML file: {path_to_use} - {exc}")
+        raise
+    if config_path is None:
+        logger.info("Config file was not specified. Default config will be used.")
+    return config
+
+
+@click.group(context_settings=dict(help_option_names=["-h", "--help"]))
+def main():
+    """seq2squiggle (MI355X engine): predicts nanopore sequencing signals with a feed-forward transformer."""
+
+
+@main.command()
+def version():
+    """Print the version."""
+    click.echo(__version__)
+
+
+@main.command(context_settings={"ignore_unknown_options": True})
+@click.argument("fasta", required=False, type=click.Path(exists=False, file_okay=True, dir_okay=False, path_type=pathlib.Path))
+@click.option("--read-input", default=False, is_flag=True, show_default=True,
+              help="Read mode: simulate signals directly from the reads of a FASTA/FASTQ file.")
+@click.option("-n", "--num-reads", type=int, default=-1, help="Number of generated reads.")
+@click.option("-r", "--read-length", type=int, default=1000, show_default=True, help="Average read length.")
+@click.option("-c", "--coverage", type=int, default=-1, help="Genome coverage.")
+@click.option("-o", "--out", required=False, type=click.Path(file_okay=True, dir_okay=False, path_type=pathlib.Path),
+              help="Output POD5/SLOW5/BLOW5 file.")
+@click.option("--profile", default="dna-r10-prom", show_default=True,
+              type=click.Choice(["dna-r10-prom", "dna-r10-min", "dna-r9-prom", "dna-r9-min", "rna-004-prom", "rna-004-min"]))
+@click.option("--show-advanced-options", is_flag=True, default=False, help="Show advanced options.")
+@click.option("--noise-sampler", default=True, type=bool, show_default=True, hidden=True)
+@click.option("--duration-sampler", default=True, type=bool, show_default=True, hidden=True)
+@click.option("--dwell-mean", default=None, type=float, hidden=True)
+@click.option("--dwell-std", default=0.0, type=float, hidden=True)
+@click.option("--noise-std", default=2.0, type=float, hidden=True)
+@click.option("--distr", default="expon", type=click.Choice(["expon", "beta", "gamma"]), hidden=True)
+@click.option("--predict-batch-size", default=1024, type=int, hidden=True)
+@click.option("--export-every-n-samples", default=1000000, type=int, hidden=True)
+@click.option("--sample-rate", default=None, type=int, hidden=True)
+@click.option("--bps", default=None, type=int, hidden=True)
+@click.option("--digitisation", default=None, type=int, hidden=True)
+@click.option("--range_val", default=None, type=float, hidden=True)
+@click.option("--offset_mean", default=None, type=float, hidden=True)
+@click.option("--offset_std", default=None, type=float, hidden=True)
+@click.option("--median_before_mean", default=None, type=float, hidden=True)
+@click.option("--median_before_std", default=None, type=float, hidden=True)
+@click.option("--min_noise", default=0.0, type=float, hidden=True)
+@click.option("--min_duration", default=3, type=int, hidden=True)
+@click.option("--min_read_len", default=30, type=int, hidden=True)
+@click.option("--preserve-read-ids", is_flag=True, default=False,
+              help="Keep the input read ids instead of generated ones.")
+@click.option("-s", "--seed", type=int, default=0, help="Seed for reproducibility (0 = random).")
+@click.option("-m", "--model", type=click.Path(exists=False, dir_okay=False), help="Model weights (.ckpt).")
+@click.option("-y", "--config", help="YAML configuration file overriding the defaults.")
+@click.option("-v", "--verbosity", type=click.Choice(["debug", "info", "warning", "error"], case_sensitive=False), default="info")
+@click.option("--compute-mode", default="f16x3", type=click.Choice(["f16x3", "f32"]), hidden=True,
+              help="Decoder arithmetic of the MI355X engine.")
+@click.pass_context
+def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profile, show_advanced_options, noise_sampler,
+            duration_sampler, dwell_mean, dwell_std, noise_std, distr, predict_batch_size, export_every_n_samples,
+            sample_rate, bps, digitisation, range_val, offset_mean, offset_std, median_before_mean, median_before_std,
+            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode):
+    """Generate nanopore signals from a reference genome (default) or from reads (--read-input)."""
+    from .inference import inference_run
+    from .utils import set_seeds, setup_logging
+
+    if show_advanced_options:
+        for p in ctx.command.params:
+            p.hidden = False
+        click.echo(ctx.get_help())
+        ctx.exit()
+    if not fasta or not out:
+        logger.error("FASTA file and Output file are required for prediction.")
+        ctx.exit(1)
+    setup_logging(verbosity)
+    logger.info("seq2squiggle (MI355X engine) version %s", str(__version__))
+    cfg = set_config(config)
+    seed = set_seeds(seed)
+    inference_run(config=cfg, saved_weights=model, fasta=str(fasta), read_input=read_input, n=num_reads, r=read_length,
+                  c=coverage, out=str(out), profile=profile, dwell_mean=dwell_mean, dwell_std=dwell_std, noise_std=noise_std,
+                  noise_sampling=noise_sampler, duration_sampling=duration_sampler, distr=distr,
+                  predict_batch_size=predict_batch_size, export_every_n_samples=export_every_n_samples,
+                  sample_rate=sample_rate, bps=bps, digitisation=digitisation, range_val=range_val,
+                  offset_mean=offset_mean, offset_std=offset_std, median_before_mean=median_before_mean,
+                  median_before_std=median_before_std, min_noise=min_noise, min_duration=min_duration,
+                  min_read_len=min_read_len, preserve_read_ids=preserve_read_ids, seed=seed, mode=compute_mode)
+    logger.info("Prediction finished.")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""Predict orchestration: the reference's inference.py (get_writer 30-82, check_model 224-267,
+inference_run 270-427) with the Lightning Trainer replaced by a plain loop over batches of chunks.
+Weight download (inference.py:85-221) needs the network and is out of scope: pass --model."""
+import logging
+import os
+from typing import Iterable, Iterator, Tuple
+
+import numpy as np
+import torch
+
+from .chunker import encode_read
+from .model import seq2squiggle
+from .parallel import rank_output_path, rank_world, shard_reads
+from .signal_io import BLOW5Writer, POD5Writer
+from .utils import get_profile, get_reads, update_config, update_profile
+
+logger = logging.getLogger("seq2squiggle")
+
+
+def get_writer(out: str, profile: object, ideal_mode: bool, export_every_n_samples: int, profile_name: str,
+               preserve_read_ids: bool) -> tuple:
+    """Writer by output extension (inference.py:30-82): deletes an existing file, creates the directory."""
+    out = str(out)
+    out_base = os.path.basename(out)
+    out_dir = os.path.dirname(out)
+    if out_dir and not os.path.exists(out_dir):
+        os.makedirs(out_dir, exist_ok=True)
+    if os.path.exists(out):
+        logger.warning(f"Output file {out} already exists. File will be deleted.")
+        os.remove(out)
+    if any(out_base.endswith(ext) for ext in (".blow5", ".slow5")):
+        return BLOW5Writer(out, profile, ideal_mode, profile_name, preserve_read_ids), export_every_n_samples
+    if out_base.endswith(".pod5"):
+        return POD5Writer(out, profile, ideal_mode, profile_name, preserve_read_ids), float("inf")
+    logger.error("Output file must have .pod5, .slow5, or .blow5 extension.")
+    raise ValueError("Output file must have .pod5, .slow5, or .blow5 extension.")
+
+
+_EXCLUDE = ("log_name", "wandb_logger_state", "max_chunks_train", "max_chunks_valid", "train_valid_split",
+            "train_batch_size", "save_model")
+
+
+def check_model(model: object, config: dict) -> None:
+    """Warn on checkpoint/config mismatches, raise on a seq_kmer mismatch (inference.py:224-267)."""
+    model_params = model.hparams.config
+    for param, value in config.items():
+        if param in _EXCLUDE or model_params.get(param) == value:
+            continue
+        if param == "seq_kmer":
+            raise ValueError(f"Parameter 'seq_kmer' mismatch: Model checkpoint value is {model_params.get(param)}, while "
+                             f"config value is {value}. The model was trained on {model_params.get(param)}-mers, while the "
+                             f"config file expects {value}-mers. Choose a different model or change the config value or "
+                             "the --profile option. ")
+        logger.warning(f"Mismatching {param} parameter in model checkpoint ({model_params.get(param)}) and in config "
+                       f"file ({value})")
+
+
+def iter_batches(reads: Iterable[Tuple[str, str]], k: int, batch_size: int, device) -> Iterator[tuple]:
+    """(read_ids, bases, n_valid) batches of up to batch_size chunks in read order: the job of load_fasta +
+    DataLoader (dataloader.py:401-453, 141-149).  Reads shorter than k yield nothing (dataloader.py:393-398)."""
+    ids, parts, nvs, n = [], [], [], 0
+    for seq, name in reads:
+        b, nv = encode_read(seq, k)
+        s = 0
+        while s < b.shape[0]:
+            take = min(batch_size - n, b.shape[0] - s)
+            ids.extend([name] * take)
+            parts.append(b[s:s + take])
+            nvs.append(nv[s:s + take])
+            n += take
+            s += take
+            if n == batch_size:
+                yield (tuple(ids), torch.from_numpy(np.concatenate(parts)).to(device),
+                       torch.from_numpy(np.concatenate(nvs)).to(device))
+                ids, parts, nvs, n = [], [], [], 0
+    if n:
+        yield tuple(ids), torch.from_numpy(np.concatenate(parts)).to(device), torch.from_numpy(np.concatenate(nvs)).to(device)
+
+
+def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool, n: int, r: int, c: int, out: str,
+                  profile: dict, dwell_mean: int, dwell_std: float, noise_std: float, noise_sampling: bool,
+                  duration_sampling: bool, distr: str, predict_batch_size: int, export_every_n_samples: int,
+                  sample_rate: int, bps: int, digitisation: int, range_val: float, offset_mean: float, offset_std: float,
+                  median_before_mean: float, median_before_std: float, min_noise: float, min_duration: float,
+                  min_read_len: int, preserve_read_ids: bool, seed: int, mode: str = "f16x3"):
+    """Same 30 parameters as the reference (inference.py:270-301) plus `mode` (decoder arithmetic)."""
+    profile_dict = get_profile(profile)
+    profile_dict = update_profile(profile_dict, sample_rate=sample_rate, bps=bps, digitisation=digitisation, range=range_val,
+                                  offset_mean=offset_mean, offset_std=offset_std, median_before_mean=median_before_mean,
+                                  median_before_std=median_before_std)
+    if dwell_mean is None:
+        dwell_mean = profile_dict["sample_rate"] / profile_dict["bps"]
+    config = update_config(profile, config)
+    ideal_mode = not (duration_sampling or dwell_std > 0)
+
+    rank, local_rank, world = rank_world()
+    writer, export_every_n_samples = get_writer(rank_output_path(str(out), rank, world), profile_dict, ideal_mode,
+                                                export_every_n_samples, profile_name=profile,
+                                                preserve_read_ids=preserve_read_ids)
+    if saved_weights is None:
+        raise FileNotFoundError("no model weights given: downloading released weights needs network access; pass "
+                                "--model <file.ckpt>")
+    reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
+    first_chunk = 0
+    if world > 1:                      # every rank derives the same read list, then keeps its contiguous share
+        reads = list(reads)
+        lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
+        reads = reads[lo:hi]
+        logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
+
+    load_model = seq2squiggle.load_from_checkpoint(
+        checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean, dwell_std=dwell_std, noise_std=noise_std,
+        noise_sampling=noise_sampling, duration_sampling=duration_sampling, export_every_n_samples=export_every_n_samples,
+        min_noise=min_noise, min_duration=min_duration, device=local_rank, mode=mode, seed=seed,
+        first_global_chunk=first_chunk)
+    check_model(load_model, config)
+
+    n_chunks = 0
+    for batch in iter_batches(reads, config["seq_kmer"], predict_batch_size, load_model.device):
+        load_model.predict_step(batch)
+        n_chunks += len(batch[0])
+    load_model.on_predict_epoch_end()
+    torch.cuda.synchronize(load_model.device)
+    logger.info(f"Predicted {n_chunks} chunks ({n_chunks * 250} padded samples).")
+    return load_model

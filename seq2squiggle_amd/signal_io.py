@@ -1,0 +1,242 @@
+"""SLOW5 / BLOW5 writers for the predict path.
+
+Reference: signal_io.py:62-172 (BLOW5Writer on pyslow5) and 175-282 (POD5Writer on pod5).  Neither
+library exists in this image, so the SLOW5 ASCII and BLOW5 binary encodings (slow5 specification
+v0.2.0) are written natively.  The writer protocol is the reference's: the model sets
+`writer.signals = {read_id: 1-D fp32 tensor}` and calls `writer.save()`; every save appends.
+
+Deviations from the reference, on purpose:
+  * read ids / read_number count over the whole run, not per save() call (the reference restarts
+    `idx` at every export batch and so writes duplicate `indexed_uuid`s, signal_io.py:123,145);
+  * BLOW5 records are zlib-compressed with uncompressed int16 signal (pyslow5's default is zlib +
+    svb-zd); both are valid BLOW5, the file is larger.
+  * POD5 is not written yet (the reference itself recommends BLOW5 + blue_crab for large runs,
+    inference.py:72-79).
+"""
+import logging
+import os
+import struct
+import uuid
+import zlib
+from datetime import datetime
+
+import numpy as np
+
+logger = logging.getLogger("seq2squiggle")
+
+
+def indexed_uuid(index: int) -> uuid.UUID:
+    """UUID-shaped incrementing id (signal_io.py:19-23)."""
+    return uuid.UUID(f"00000000-0000-0000-0000-{index:012d}")
+
+
+_KITS = {
+    "rna-004": {"seq_kit": "sqk-rna004", "prom": "FLO-PRO004RA", "min": "FLO-MIN004RA"},
+    "rna-002": {"seq_kit": "sqk-rna002", "prom": "FLO-PRO002", "min": "FLO-MIN106"},
+    "dna-r10": {"seq_kit": "SQK-LSK114", "prom": "FLO-PRO114", "min": "FLO-MIN114"},
+    "dna-r9": {"seq_kit": "SQK-LSK109", "prom": "FLO-PRO001", "min": "FLO-MIN110"},
+}
+
+
+def get_seq_kit_and_flow_cell(profile_name: str):
+    """(sequencing kit, flow cell product code) of a profile (signal_io.py:26-60)."""
+    for prefix, data in _KITS.items():
+        if profile_name.startswith(prefix):
+            key = "prom" if "prom" in profile_name else "min" if "min" in profile_name else None
+            if key is None:
+                break
+            return data["seq_kit"], data[key]
+    raise ValueError(f"Unsupported profile name: {profile_name}")
+
+
+def signal_to_dac(signal: np.ndarray, digitisation: float, signal_range: float, offset: float, rna: bool) -> np.ndarray:
+    """pA -> int16 (signal_io.py:134-141): float32 arithmetic, round-half-even, C cast (wraps)."""
+    s = np.asarray(signal, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        raw = np.round(s * float(digitisation) / float(signal_range) - float(offset))
+    raw = raw.astype(np.int64).astype(np.int16)
+    return np.ascontiguousarray(raw[::-1]) if rna else raw
+
+
+_COLS = ("read_id", "read_group", "digitisation", "offset", "range", "sampling_rate", "len_raw_signal", "raw_signal",
+         "channel_number", "median_before", "read_number", "start_mux", "start_time")
+_TYPES = ("char*", "uint32_t", "double", "double", "double", "double", "uint64_t", "int16_t*",
+          "char*", "double", "int32_t", "uint8_t", "uint64_t")
+
+
+def _fmt_double(x: float) -> str:
+    return repr(float(x))
+
+
+class BLOW5Writer:
+    """Writes `.slow5` (ASCII) or `.blow5` (binary) by the file extension."""
+
+    def __init__(self, filename, profile, ideal_mode, profile_name, preserve_read_ids):
+        self.filename = str(filename)
+        self.profile = profile
+        self.ideal_mode = ideal_mode
+        self.profile_name = profile_name
+        self.preserve_read_ids = preserve_read_ids
+        self.signals = None
+        self.dac = None                       # optional {read_id: int16 array} computed on the GPU
+        self.median_before = float(profile["median_before_mean"])
+        self.median_before_std = float(profile["median_before_std"])
+        self.offset = float(profile["offset_mean"])
+        self.offset_std = float(profile["offset_std"])
+        self.digitisation = float(profile["digitisation"])
+        self.signal_range = float(profile["range"])
+        self.sample_rate = float(profile["sample_rate"])
+        self.start_time = 0
+        self.n_written = 0
+        self.binary = self.filename.endswith(".blow5")
+
+    # ------------------------------------------------------------------ header
+    def header_attributes(self) -> dict:
+        seq_kit, flow_cell = get_seq_kit_and_flow_cell(self.profile_name)
+        return {
+            "asic_id": "asic_id_0",
+            "exp_start_time": datetime.now().strftime("%Y-%m-%dT%H:%M:%SZ"),
+            "run_id": "run_id_0",
+            "flow_cell_id": "FAN00000",
+            "flow_cell_product_code": flow_cell,
+            "experiment_type": "rna" if self.profile_name.startswith("rna") else "genomic_dna",
+            "sample_frequency": int(self.sample_rate),
+            "sequencing_kit": seq_kit,
+        }
+
+    def _header_text(self) -> str:
+        lines = ["#slow5_version\t0.2.0", "#num_read_groups\t1"]
+        for k, v in sorted(self.header_attributes().items()):
+            lines.append(f"@{k}\t{v}")
+        lines.append("#" + "\t".join(_TYPES))
+        lines.append("#" + "\t".join(_COLS))
+        return "\n".join(lines) + "\n"
+
+    # ------------------------------------------------------------------ records
+    def records(self):
+        """The records of the current `signals`, as the reference builds them (signal_io.py:123-161)."""
+        rna = self.profile_name.startswith("rna")
+        for read_id, signal in self.signals.items():
+            if len(signal) == 0:
+                logger.debug("Empty signal, skipping {}".format(read_id))
+                continue
+            if self.ideal_mode:
+                median_before_value, offset_value = self.median_before, self.offset
+            else:
+                median_before_value = np.random.normal(self.median_before, self.median_before_std)
+                offset_value = np.random.normal(self.offset, self.offset_std)
+            if self.dac is not None and read_id in self.dac:
+                raw = np.asarray(self.dac[read_id], dtype=np.int16)
+            else:
+                sig = signal.detach().cpu().numpy() if hasattr(signal, "detach") else np.asarray(signal)
+                raw = signal_to_dac(sig, self.digitisation, self.signal_range, self.offset, rna)
+            self.n_written += 1
+            rid = read_id if self.preserve_read_ids else indexed_uuid(self.n_written)
+            rec = {"read_id": str(rid), "read_group": 0, "digitisation": self.digitisation, "offset": offset_value,
+                   "range": self.signal_range, "sampling_rate": self.sample_rate, "len_raw_signal": len(raw),
+                   "signal": raw, "channel_number": "0", "median_before": median_before_value,
+                   "read_number": self.n_written - 1, "start_mux": 0, "start_time": self.start_time}
+            self.start_time += len(raw)
+            yield rec
+
+    def save(self):
+        if self.signals is None:
+            logger.warning("SLOW5 was not exported. No signals were found")
+            raise ValueError("SLOW5 was not exported. No signals were found")
+        append = os.path.exists(self.filename)
+        if self.binary:
+            self._save_blow5(append)
+        else:
+            self._save_slow5(append)
+
+    def _save_slow5(self, append: bool):
+        with open(self.filename, "a" if append else "w") as f:
+            if not append:
+                f.write(self._header_text())
+            for r in self.records():
+                f.write("\t".join([r["read_id"], str(r["read_group"]), _fmt_double(r["digitisation"]),
+                                   _fmt_double(r["offset"]), _fmt_double(r["range"]), _fmt_double(r["sampling_rate"]),
+                                   str(r["len_raw_signal"]), ",".join(map(str, r["signal"].tolist())),
+                                   r["channel_number"], _fmt_double(r["median_before"]), str(r["read_number"]),
+                                   str(r["start_mux"]), str(r["start_time"])]) + "\n")
+
+    # BLOW5 v0.2.0: 64-byte file header, u32 size + ASCII header, records (u64 size + zlib stream), "5WOLB"
+    _EOF = b"5WOLB"
+
+    def _save_blow5(self, append: bool):
+        if append:
+            with open(self.filename, "r+b") as f:      # drop the end-of-file marker, then append
+                f.seek(-len(self._EOF), os.SEEK_END)
+                if f.read(len(self._EOF)) == self._EOF:
+                    f.seek(-len(self._EOF), os.SEEK_END)
+                    f.truncate()
+        with open(self.filename, "ab" if append else "wb") as f:
+            if not append:
+                hdr = self._header_text().encode()
+                fh = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1]) + struct.pack("<I", 1) + bytes([0])
+                f.write(fh + bytes(64 - len(fh)))
+                f.write(struct.pack("<I", len(hdr)) + hdr)
+            for r in self.records():
+                rid, ch = r["read_id"].encode(), r["channel_number"].encode()
+                body = (struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", r["read_group"], r["digitisation"],
+                                                                          r["offset"], r["range"], r["sampling_rate"],
+                                                                          r["len_raw_signal"])
+                        + r["signal"].astype("<i2").tobytes()
+                        + struct.pack("<H", len(ch)) + ch
+                        + struct.pack("<diBQ", r["median_before"], r["read_number"], r["start_mux"], r["start_time"]))
+                z = zlib.compress(body)
+                f.write(struct.pack("<Q", len(z)) + z)
+            f.write(self._EOF)
+
+
+def read_blow5(path):
+    """Minimal reader of the files written above (tests / round-trip only)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    assert data[:6] == b"BLOW5\x01" and data[-5:] == BLOW5Writer._EOF
+    hlen = struct.unpack_from("<I", data, 64)[0]
+    header = data[68:68 + hlen].decode()
+    pos, recs = 68 + hlen, []
+    while pos < len(data) - 5:
+        n = struct.unpack_from("<Q", data, pos)[0]
+        body = zlib.decompress(data[pos + 8:pos + 8 + n])
+        pos += 8 + n
+        o = 0
+        (ln,) = struct.unpack_from("<H", body, o); o += 2
+        rid = body[o:o + ln].decode(); o += ln
+        rg, dig, off, rng, sr, nsig = struct.unpack_from("<IddddQ", body, o); o += struct.calcsize("<IddddQ")
+        sig = np.frombuffer(body, dtype="<i2", count=nsig, offset=o); o += 2 * nsig
+        (cl,) = struct.unpack_from("<H", body, o); o += 2
+        ch = body[o:o + cl].decode(); o += cl
+        mb, rn, mux, st_ = struct.unpack_from("<diBQ", body, o)
+        recs.append({"read_id": rid, "read_group": rg, "digitisation": dig, "offset": off, "range": rng,
+                     "sampling_rate": sr, "len_raw_signal": nsig, "signal": sig, "channel_number": ch,
+                     "median_before": mb, "read_number": rn, "start_mux": mux, "start_time": st_})
+    return header, recs
+
+
+def read_slow5(path):
+    """Minimal SLOW5 ASCII reader (tests only)."""
+    header, recs = [], []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith(("#", "@")):
+                header.append(line)
+                continue
+            v = line.split("\t")
+            recs.append({"read_id": v[0], "read_group": int(v[1]), "digitisation": float(v[2]), "offset": float(v[3]),
+                         "range": float(v[4]), "sampling_rate": float(v[5]), "len_raw_signal": int(v[6]),
+                         "signal": np.array(v[7].split(","), dtype=np.int16) if v[7] else np.zeros(0, np.int16),
+                         "channel_number": v[8], "median_before": float(v[9]), "read_number": int(v[10]),
+                         "start_mux": int(v[11]), "start_time": int(v[12])})
+    return "\n".join(header) + "\n", recs
+
+
+class POD5Writer:
+    """Placeholder with the reference's constructor signature (signal_io.py:175-199)."""
+
+    def __init__(self, filename, profile, ideal_mode, profile_name, preserve_read_ids):
+        raise NotImplementedError("POD5 output is not available in this build (no pod5 library, native writer pending); "
+                                  "write .blow5/.slow5 and convert with blue_crab, as the reference recommends for "
+                                  "large runs")

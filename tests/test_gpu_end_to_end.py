@@ -1,0 +1,128 @@
+"""GPU end-to-end: model object + batching + export + writer + CLI against reference-derived expectations.
+
+Deterministic configuration (BASELINE.json configs[0]: example/test.fasta --read-input, samplers off, ideal
+dwell): the reference's own predict_step output for these chunks is the golden `y_ideal`; per read the expected
+file content is zero-strip + DAC of those rows (both pinned separately against the reference)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import seq2squiggle_amd as S
+from seq2squiggle_amd import signal_io
+from seq2squiggle_amd import utils as U
+from seq2squiggle_amd.inference import inference_run, iter_batches
+from seq2squiggle_amd.model import seq2squiggle
+from oracle import s2s_oracle as O
+from conftest import GOLDEN, ROOT, load_npz
+
+pytestmark = pytest.mark.gpu
+FASTA = os.path.join(GOLDEN, "example_test.fasta")
+
+
+def expected_records(tag, profile_name):
+    g = load_npz(f"stages_{tag}.npz")
+    names = [str(n) for n in g["names"]]
+    p = U.get_profile(profile_name)
+    out = {}
+    for rid in dict.fromkeys(names):
+        rows = [torch.from_numpy(g["y_ideal"][i]) for i, n in enumerate(names) if n == rid]
+        pa = O.strip_zeros(rows).numpy()
+        out[rid] = (pa, O.to_dac(pa, p["digitisation"], p["range"], p["offset_mean"]))
+    return out
+
+
+def check_file(path, exp, ids):
+    _, recs = (signal_io.read_slow5 if str(path).endswith(".slow5") else signal_io.read_blow5)(str(path))
+    assert [r["read_id"] for r in recs] == ids
+    for r in recs:
+        pa, dac = exp[r["read_id"]]
+        assert r["len_raw_signal"] == len(dac)
+        # |pA error| < 2e-3 -> at most one DAC step of difference, and only at rounding ties
+        d = np.abs(r["signal"].astype(np.int32) - dac.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 0.01
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("tag,profile_name", [("k9", "dna-r10-prom"), ("k6", "dna-r9-min")])
+def test_model_object_export_flow(tmp_path, mode, tag, profile_name):
+    exp = expected_records(tag, profile_name)
+    reads = [(s, n) for s, n in U.read_fasta(FASTA)]
+    w = signal_io.BLOW5Writer(str(tmp_path / "o.blow5"), U.get_profile(profile_name), True, profile_name, True)
+    m = seq2squiggle.load_from_checkpoint(os.path.join(GOLDEN, f"synthetic_{tag}.ckpt"), out_writer=w, dwell_mean=12.5,
+                                          dwell_std=0.0, noise_std=0.0, noise_sampling=False, duration_sampling=False,
+                                          export_every_n_samples=16, min_noise=0.0, min_duration=3, mode=mode)
+    k = m.config["seq_kmer"]
+    saves = 0
+    for batch in iter_batches(reads, k, 10, m.device):         # batches straddle reads; export every 16 chunks
+        before = len(m.results)
+        m.predict_step(batch)
+        saves += len(m.results) <= 1 and before >= 1
+    m.on_predict_epoch_end()
+    assert saves >= 2 and m.results == []
+    check_file(tmp_path / "o.blow5", exp, [n for _, n in reads])
+
+
+def test_reference_style_onehot_batch(tmp_path):
+    """predict_step also accepts the reference's own batch format (tuple[str], fp16 one-hot [B,16,k,5])."""
+    g = load_npz("stages_k9.npz")
+    codes = torch.from_numpy(g["codes"].astype(np.int64))
+    oh = torch.zeros(*codes.shape, 5, dtype=torch.float16)
+    oh.scatter_(-1, codes.clamp(max=4).unsqueeze(-1), (codes < 5).unsqueeze(-1).to(torch.float16))
+
+    class W:
+        signals = None
+
+        def save(self):
+            self.saved = dict(self.signals)
+    w = W()
+    m = seq2squiggle.load_from_checkpoint(os.path.join(GOLDEN, "synthetic_k9.ckpt"), out_writer=w, dwell_mean=12.5, noise_std=0.0,
+                                          min_duration=3, mode="f32")
+    m.predict_step((tuple(str(n) for n in g["names"]), oh))
+    m.on_predict_epoch_end()
+    sig = load_npz("signals_k9.npz")                         # same chunks, noise on in that golden -> compare lengths to ideal instead
+    for rid in dict.fromkeys(str(n) for n in g["names"]):
+        rows = [torch.from_numpy(g["y_ideal"][i]) for i, n in enumerate(g["names"]) if str(n) == rid]
+        ref = O.strip_zeros(rows).numpy()
+        got = w.saved[rid].cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-3
+
+
+def test_inference_run_and_cli(tmp_path):
+    exp = expected_records("k9", "dna-r10-prom")
+    ids = [n for _, n in U.read_fasta(FASTA)]
+    from seq2squiggle_amd.cli import set_config
+    out = tmp_path / "run.slow5"
+    inference_run(config=set_config(None), saved_weights=os.path.join(GOLDEN, "synthetic_k9.ckpt"), fasta=FASTA, read_input=True,
+                  n=-1, r=1000, c=-1, out=str(out), profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0, noise_std=0.0,
+                  noise_sampling=False, duration_sampling=False, distr="expon", predict_batch_size=1024,
+                  export_every_n_samples=1000000, sample_rate=None, bps=None, digitisation=None, range_val=None,
+                  offset_mean=None, offset_std=None, median_before_mean=None, median_before_std=None, min_noise=0.0,
+                  min_duration=3, min_read_len=30, preserve_read_ids=True, seed=1)
+    check_file(out, exp, ids)
+    out2 = tmp_path / "cli.blow5"
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict", FASTA, "--read-input", "-o", str(out2), "-m",
+                        os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--noise-std", "0", "--noise-sampler", "False",
+                        "--duration-sampler", "False", "--preserve-read-ids", "--seed", "1"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    check_file(out2, exp, ids)
+    # default samplers on, reference mode, sampled reads: runs and writes the requested number of reads
+    out3 = tmp_path / "ref.blow5"
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict", os.path.join(GOLDEN, "example_lambda_genome.fasta"),
+                        "-n", "20", "-r", "2000", "-o", str(out3), "-m", os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--seed", "3"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, recs = signal_io.read_blow5(str(out3))
+    assert len(recs) == 20 and all(r_["len_raw_signal"] > 100 for r_ in recs)
+    assert recs[1]["read_id"] == "00000000-0000-0000-0000-000000000002"
+    with pytest.raises(ValueError):                          # seq_kmer mismatch: k=9 checkpoint with an r9 profile
+        inference_run(config=set_config(None), saved_weights=os.path.join(GOLDEN, "synthetic_k9.ckpt"), fasta=FASTA,
+                      read_input=True, n=-1, r=1000, c=-1, out=str(tmp_path / "x.slow5"), profile="dna-r9-min", dwell_mean=None,
+                      dwell_std=0.0, noise_std=0.0, noise_sampling=False, duration_sampling=False, distr="expon",
+                      predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None, bps=None, digitisation=None,
+                      range_val=None, offset_mean=None, offset_std=None, median_before_mean=None, median_before_std=None,
+                      min_noise=0.0, min_duration=3, min_read_len=30, preserve_read_ids=True, seed=1)

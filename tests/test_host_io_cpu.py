@@ -1,0 +1,190 @@
+"""CPU tests of the host side around the hot path: writers, model-object helpers, batching, sharding, CLI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from seq2squiggle_amd import chunker, parallel, signal_io
+from seq2squiggle_amd import utils as U
+from conftest import GOLDEN, ROOT, load_npz
+
+
+def _writer(path, profile_name="dna-r10-prom", ideal=True, preserve=True):
+    return signal_io.BLOW5Writer(str(path), U.get_profile(profile_name), ideal, profile_name, preserve)
+
+
+@pytest.mark.parametrize("tag,profile_name", [("k9", "dna-r10-prom"), ("k6", "dna-r9-min")])
+@pytest.mark.parametrize("ext", [".slow5", ".blow5"])
+def test_writer_records_match_reference_writer(tmp_path, tag, profile_name, ext):
+    """Feed the reference's per-read pA signals to the native writer: header attributes, int16 samples and record
+    fields must equal what the reference's BLOW5Writer.save handed to pyslow5 (export_*.npz)."""
+    sig = load_npz(f"signals_{tag}.npz")
+    ex = load_npz(f"export_{tag}.npz")
+    w = _writer(tmp_path / ("o" + ext), profile_name)
+    order = [str(x) for x in sig["read_order"]]
+    half = len(order) // 2
+    for part in (order[:half], order[half:]):                     # two save() calls: append mode
+        w.signals = {rid: torch.from_numpy(sig["sig__" + rid]) for rid in part}
+        w.save()
+    header, recs = (signal_io.read_slow5 if ext == ".slow5" else signal_io.read_blow5)(str(tmp_path / ("o" + ext)))
+    attrs = dict(line[1:].split("\t") for line in header.splitlines() if line.startswith("@"))
+    for k, v in zip(ex["header_keys"], ex["header_vals"]):
+        assert attrs[str(k)] == str(v), k
+    assert "exp_start_time" in attrs
+    ref = {}
+    for key in ex["order"]:
+        rid = str(key).split("__", 1)[1]
+        ref[rid] = (ex[str(key) + "__raw"], ex[str(key) + "__meta"])
+    assert [r["read_id"] for r in recs] == order
+    t = 0
+    for i, r in enumerate(recs):
+        raw, meta = ref[r["read_id"]]
+        assert np.array_equal(r["signal"], raw)
+        assert (r["digitisation"], r["offset"], r["range"], r["sampling_rate"], r["len_raw_signal"],
+                r["median_before"]) == tuple(meta[:6])
+        assert r["start_time"] == t and r["read_number"] == i and r["channel_number"] == "0" and r["start_mux"] == 0
+        t += len(raw)
+
+
+def test_writer_ids_rna_and_errors(tmp_path):
+    w = _writer(tmp_path / "a.slow5", "rna-004-prom", ideal=False, preserve=False)
+    with pytest.raises(ValueError):
+        w.save()
+    np.random.seed(0)
+    w.signals = {"x": torch.tensor([100.0, 101.0, 0.5]), "empty": torch.zeros(0), "y": torch.tensor([50.0])}
+    w.save()
+    _, recs = signal_io.read_slow5(str(tmp_path / "a.slow5"))
+    assert [r["read_id"] for r in recs] == ["00000000-0000-0000-0000-000000000001", "00000000-0000-0000-0000-000000000002"]
+    p = U.get_profile("rna-004-prom")
+    exp = signal_io.signal_to_dac(np.array([100.0, 101.0, 0.5], np.float32), p["digitisation"], p["range"], p["offset_mean"], True)
+    assert np.array_equal(recs[0]["signal"], exp) and recs[0]["offset"] != p["offset_mean"]    # sampled offset, mean in the DAC
+    assert signal_io.get_seq_kit_and_flow_cell("dna-r9-min") == ("SQK-LSK109", "FLO-MIN110")
+    with pytest.raises(ValueError):
+        signal_io.get_seq_kit_and_flow_cell("dna-r7")
+    with pytest.raises(NotImplementedError):
+        signal_io.POD5Writer("x.pod5", p, True, "rna-004-prom", False)
+
+
+def test_onehot_to_bases_equals_chunker():
+    from seq2squiggle_amd.model import onehot_to_bases
+    lut = np.full(256, 255, np.uint8)
+    for i, ch in enumerate("_ACGT"):
+        lut[ord(ch)] = i
+    for tag, k in (("k9", 9), ("k6", 6)):
+        codes = load_npz(f"stages_{tag}.npz")["codes"]
+        oh = torch.zeros(*codes.shape, 5, dtype=torch.float16)
+        c = torch.from_numpy(codes.astype(np.int64))
+        oh.scatter_(-1, c.clamp(max=4).unsqueeze(-1), (c < 5).unsqueeze(-1).to(torch.float16))
+        bases, nv = onehot_to_bases(oh)
+        bases, nv = bases.numpy(), nv.numpy()
+        for b in range(codes.shape[0]):
+            for j in range(16):
+                got = lut[bases[b, j:j + k]] if j < nv[b] else np.zeros(k, np.uint8)
+                assert np.array_equal(got, codes[b, j]), (tag, b, j)
+
+
+def test_iter_batches_order_and_sizes():
+    from seq2squiggle_amd.inference import iter_batches
+    reads = [("ACGT" * 30, "a"), ("AC", "too_short"), ("ACGTT" * 50, "b"), ("A" * 9, "c")]
+    batches = list(iter_batches(reads, 9, 5, "cpu"))
+    ids = [i for b in batches for i in b[0]]
+    assert ids == ["a"] * 7 + ["b"] * 16 + ["c"]
+    assert [len(b[0]) for b in batches] == [5, 5, 5, 5, 4]
+    allb = torch.cat([b[1] for b in batches]).numpy()
+    exp = np.concatenate([chunker.encode_read(s, 9)[0] for s, _ in reads])
+    assert np.array_equal(allb, exp)
+
+
+def test_get_writer_and_check_model(tmp_path):
+    from seq2squiggle_amd.inference import check_model, get_writer
+    from types import SimpleNamespace
+    p = U.get_profile("dna-r10-prom")
+    existing = tmp_path / "sub" / "o.blow5"
+    os.makedirs(existing.parent)
+    existing.write_text("old")
+    w, n = get_writer(str(existing), p, True, 123, "dna-r10-prom", False)
+    assert isinstance(w, signal_io.BLOW5Writer) and n == 123 and not existing.exists()
+    with pytest.raises(ValueError):
+        get_writer(str(tmp_path / "o.fast5"), p, True, 1, "dna-r10-prom", False)
+    m = SimpleNamespace(hparams=SimpleNamespace(config={"seq_kmer": 9, "dff": 256, "log_name": "x"}))
+    check_model(m, {"seq_kmer": 9, "dff": 128, "log_name": "y"})           # warns only
+    with pytest.raises(ValueError):
+        check_model(m, {"seq_kmer": 6})
+
+
+def test_shard_reads_properties():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(5, 9000, size=500).tolist()
+    for world in (1, 2, 3, 8):
+        sh = parallel.shard_reads(lens, 9, world)
+        assert sh[0][0] == 0 and sh[-1][1] == len(lens)
+        total = sum(chunker.n_chunks(L, 9) for L in lens)
+        for r in range(world):
+            lo, hi, first = sh[r]
+            assert first == sum(chunker.n_chunks(L, 9) for L in lens[:lo])
+            if r:
+                assert lo == sh[r - 1][1]
+            n = sum(chunker.n_chunks(L, 9) for L in lens[lo:hi])
+            assert abs(n - total / world) <= max(chunker.n_chunks(L, 9) for L in lens)
+    assert parallel.rank_output_path("a/b.blow5", 3, 8) == "a/b.rank3.blow5"
+    assert parallel.rank_output_path("a/b.blow5", 0, 1) == "a/b.blow5"
+
+
+_DIST_WORKER = r"""
+import os, sys, zlib, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from seq2squiggle_amd import parallel, utils as U
+from seq2squiggle_amd.chunker import n_chunks
+dist.init_process_group("gloo")
+rank, local, world = parallel.rank_world()
+assert (rank, world) == (dist.get_rank(), dist.get_world_size())
+import random
+random.seed(5)
+genome, lens = U.preprocess_genome(sys.argv[2])
+reads, _ = U.sample_reads_from_reference(genome, lens, 40, 3000, -1, {"max_dna_len": 16}, "x", 5)
+reads = list(reads)
+lo, hi, first = parallel.shard_reads([len(s) for s, _ in reads], 9, world)[rank]
+mine = torch.tensor([lo, hi, first, sum(n_chunks(len(s), 9) for s, _ in reads[lo:hi]),
+                     zlib.crc32(''.join(s for s, _ in reads).encode())], dtype=torch.int64)
+out = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(out, mine)
+if rank == 0:
+    assert out[0][0] == 0 and out[-1][1] == len(reads)
+    for r in range(1, world):
+        assert out[r][0] == out[r - 1][1] and out[r][2] == out[r - 1][2] + out[r - 1][3]
+        assert out[r][4] == out[0][4]            # every rank derived the same read set from the seed
+    print("SHARDS_OK", [o.tolist()[:4] for o in out])
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharding_over_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_DIST_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT,
+                        os.path.join(GOLDEN, "example_lambda_genome.fasta")], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert "SHARDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cli_surface():
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 1 and "required" in r.stderr + r.stdout
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict", "--show-advanced-options"], cwd=ROOT,
+                       capture_output=True, text=True)
+    for opt in ("--noise-sampler", "--duration-sampler", "--dwell-mean", "--dwell-std", "--noise-std", "--distr",
+                "--predict-batch-size", "--export-every-n-samples", "--sample-rate", "--bps", "--digitisation", "--range_val",
+                "--offset_mean", "--offset_std", "--median_before_mean", "--median_before_std", "--min_noise", "--min_duration",
+                "--min_read_len", "--preserve-read-ids", "--read-input", "--num-reads", "--read-length", "--coverage",
+                "--profile", "--seed", "--model", "--config", "--verbosity"):
+        assert opt in r.stdout, opt
+    from seq2squiggle_amd.cli import set_config
+    cfg = set_config(None)
+    assert cfg["seq_kmer"] == 9 and cfg["dmodel"] == 64 and cfg["max_signal_len"] == 250 and cfg["scaling_max_value"] == 165.0
+    with pytest.raises(FileNotFoundError):
+        set_config("/nonexistent.yaml")
