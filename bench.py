@@ -41,6 +41,22 @@ def make_reads(n_reads, seed):
     return [lut[c].tobytes().decode() for c in codes]
 
 
+def pmc_traffic(mode, chunks_per_launch):
+    """HBM bytes per decoder launch from the committed PMC passes (tools/pmc_run.sh -> profiles/*/pmc_summary.json):
+    (2 x FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half of a wide coalesced read on gfx950
+    (MI355X_MICROARCH.md, HBM) -- measured per 32,768-chunk dispatch and scaled to this run's launch size."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path)).get(mode, {})
+            k = next(k for k in d if "decoder" in k)
+            per_chunk = (2 * d[k]["FETCH_SIZE"] + d[k]["WRITE_SIZE"]) * 1024 / 32768
+            return per_chunk * chunks_per_launch, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline(sd, cfg, seconds_target=12.0):
     """Oracle (CPU port of the reference op sequence, torch fp32 'highest') on the host cores."""
     from oracle import s2s_oracle as O
@@ -127,6 +143,8 @@ def main():
         chunks_total = B * a.steps * world
         chunks_s = chunks_total / el
         tflops = FLOP_PER_CHUNK_DECODER * dec_chunks / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else None
+        cpl = dec_chunks / dec_launches if dec_launches else None
+        traffic, traffic_src = pmc_traffic(a.mode, cpl) if cpl else (None, None)
         out = {
             "metric": "signal samples/sec at 5 kb reads (padded [chunks x 250] samples the predict path emits)",
             "value": chunks_s * 250, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -140,7 +158,9 @@ def main():
             "emitted_samples_per_sec": emitted * world / (el / a.steps),
             "roofline": {"bound": "mfma", "kernel": "s2s_decoder_kernel", "achieved": tflops,
                          "peak": PEAK[a.mode], "unit": "TFLOP/s",
-                         "frac": (tflops / PEAK[a.mode]) if tflops else None, "traffic": None,
+                         "frac": (tflops / PEAK[a.mode]) if tflops else None, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, separate profiled run)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": 1088 * cpl if cpl else None,
                          "peak_note": ("f32-input MFMA peak" if a.mode == "f32" else
                                        "dense f16 MFMA peak / 3 products per algorithmic product; achieved counts algorithmic flops"),
                          "flop_per_chunk": FLOP_PER_CHUNK_DECODER,

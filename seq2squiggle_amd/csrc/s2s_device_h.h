@@ -244,7 +244,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt)
-                            s[q][kt] = (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+                            s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
                     // per-lane partial maxima; the cross-lane reduction is only needed in pass 0 and on the
                     // (rare) raise path -- the raise test itself is a wave-wide vote on the partial maxima
                     float mh[NQ];
@@ -299,6 +299,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         }
 #pragma unroll
                         for (int kb = 0; kb < HB; ++kb) {
+                            if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
                             oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
                             oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
                             if (!(S2S_ABL & 64)) {
