@@ -23,13 +23,13 @@ struct LayerOff {
     int bq_nat, bk_nat;                     // bq/bk in natural row order (f16 block)
     int ln1g, ln1b, ln2g, ln2b;
 };
-struct MlpOff { int w0, b0, w3, b3; };
+struct MlpOff { int w0, b0, w3, b3, w0h; };   // w0h: the 64x64 layer as 4 f16 hi/lo units
 struct ModelDev {
     int k, enc_layers, dec_layers, pre_layers;
     float scale;                            // scaling_max_value
     int pe_enc, pe_dec;                     // [T][64] natural
     int emb_wt, emb_b;                      // W_emb^T [5k][64], bias [64]
-    int pre_w[S2S_MAX_LAYERS], pre_b[S2S_MAX_LAYERS];
+    int pre_w[S2S_MAX_LAYERS], pre_b[S2S_MAX_LAYERS], pre_wh[S2S_MAX_LAYERS];
     LayerOff enc[S2S_MAX_LAYERS], dec[S2S_MAX_LAYERS];
     MlpOff noise, conc, rate;
     int out_w, out_b;

@@ -80,11 +80,12 @@ __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h
     lo = __builtin_bit_cast(h4, (uv2{l0, l1}));
 }
 
-// LDS of the f16 block (NKT = 16 key tiles): K [head][hi|lo][key][8 d] halves, V^T [head][16 rows:
-// 0-7 hi d, 8-15 lo d][VS keys] halves, and a per-wave scratch for the Q^T operand re-layout.
-template <int NQ, int WAVES> struct AttnLdsH {
-    static constexpr int K_BYTES = 8 * 2 * 256 * 8 * 2;
-    static constexpr int VS = 264;                        // halves per V row: (VS/2) % 64 == 4 -> conflict-free b64 reads
+// LDS of the f16 block: K [head][hi|lo][key][8 d] halves, V^T [head][16 rows: 0-7 hi d, 8-15 lo d][VS keys]
+// halves, and a per-wave scratch for the Q^T operand re-layout.
+template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
+    static constexpr int KEYS = 16 * NKT;
+    static constexpr int K_BYTES = 8 * 2 * KEYS * 8 * 2;
+    static constexpr int VS = KEYS + 8;                   // halves per V row; 264: (VS/2) % 64 == 4 -> conflict-free b64 reads
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
     static constexpr int BYTES = K_BYTES + V_BYTES + WAVES * Q_WAVE_BYTES;
@@ -106,13 +107,27 @@ __device__ __forceinline__ void mm_unit_h(f32x4 (&acc)[NQ], const f32x4 (&f)[4],
     }
 }
 
-// One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h; T = 250 only.
-template <int NQ, int WAVES, int TV>
+// y = W x + b for a 64x64 Linear stored as 4 f16 units (one per 16-row m-tile), single time tile.
+__device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const float* __restrict__ bias, int lane,
+                                           const HL (&xb)[1][2], f32x4 (&y)[1][4]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x4 f[4], t[1];
+        load_unit(f, wu + mt * 1024 + lane * 4);
+        t[0] = f32x4{0, 0, 0, 0};
+        mm_unit_h<1>(t, f, xb);
+        y[0][mt] = t[0] + ldg4(bias + 16 * mt + 4 * g);
+    }
+}
+
+// One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
+template <int NQ, int WAVES, int NKT, int TV>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr) {
-    using G = AttnLdsH<NQ, WAVES>;
-    constexpr int NKT = 16, NH = 4, HK = NKT / NH, HB = HK / 2;   // 4 passes of 64 keys
+    using G = AttnLdsH<NQ, WAVES, NKT>;
+    constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
     constexpr float THR = 8.0f;                                  // deferred-max threshold (log2 units)
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
@@ -151,8 +166,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             const int key = 16 * (qt0 + q) + c;
             h4 hi, lo;
             split4(ak[q] + bk, one, hi, lo);
-            *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * 256 + key) * 8 + d0) = hi;
-            *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * 256 + key) * 8 + d0) = lo;
+            *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
+            *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
             split4(av[q] + bv, one, hi, lo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -209,7 +224,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     qb[q] = *reinterpret_cast<const h8*>(Ql + (((q * 2 + (g & 1)) * 2 + hh) * 16 + c) * 8);
-                const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * 256 + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
+                const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ], negm[NQ];
                 float m[NQ];
@@ -232,8 +247,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
 #pragma unroll
                     for (int kb = 0; kb < HB; ++kb) {
-                        const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (2 * (h2 * HB + kb)));
-                        const h4 v1 = *reinterpret_cast<const h4*>(vp + 16 * (2 * (h2 * HB + kb) + 1));
+                        const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
+                        h4 v1 = h4{0, 0, 0, 0};                        // a K = 32 block past the last key tile: zero keys
+                        if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
                         va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -291,9 +307,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                         for (int kb = 0; kb < HB; ++kb) {
-                            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+                            unsigned h0, h1, h2_ = 0, h3 = 0, l0, l1, l2 = 0, l3 = 0;
                             exp_split4(s[q][2 * kb], one, h0, h1, l0, l1);
-                            exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
+                            if (2 * kb + 1 < HK) exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
                             P[q][kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
                             P[q][kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
                         }

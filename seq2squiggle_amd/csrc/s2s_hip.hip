@@ -27,13 +27,18 @@ __device__ __forceinline__ void relu_tiles(f32x4 (&x)[1][MT]) {
 }
 
 // Linear(64,64)+ReLU+Linear(64,1)+Softplus on emb_out (modules.py:267-278, 182-195).
+template <int MODE>
 __device__ __forceinline__ float mlp_head(const float* __restrict__ W, const MlpOff m, const f32x4 (&s)[1][4],
-                                          int lane) {
+                                          const HL (&sb)[1][2], int lane) {
     const int g = lane >> 4;
     f32x4 hid[1][4];
+    if (MODE == 1) {
+        linear64_h(W + m.w0h, W + m.b0, lane, sb, hid);
+    } else {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) hid[0][mt] = ldg4(W + m.b0 + 16 * mt + 4 * g);
-    gemm_acc<1, 4, 4>(W + m.w0, lane, hid, s);
+        for (int mt = 0; mt < 4; ++mt) hid[0][mt] = ldg4(W + m.b0 + 16 * mt + 4 * g);
+        gemm_acc<1, 4, 4>(W + m.w0, lane, hid, s);
+    }
     relu_tiles<4>(hid);
     float part = 0.0f;
 #pragma unroll
@@ -49,12 +54,17 @@ __device__ __forceinline__ int base_code(unsigned char ch) {       // utils.py:7
     return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'T' ? 4 : ch == '_' ? 0 : -1;
 }
 
+template <int MODE>   // 0: f32-input MFMA, 1: split-f16 (s2s_device_h.h)
 __global__ __launch_bounds__(64) void s2s_frontend_kernel(
     const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
     const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
     const float* __restrict__ inj_g, const float* __restrict__ inj_zdw, float* __restrict__ ws_enc,
     float* __restrict__ ws_sigma, int* __restrict__ out_dur, DebugDev dbg, long long dbg_base) {
-    __shared__ __attribute__((aligned(16))) float lds[AttnLds<1>::FLOATS];
+    constexpr int LDS_BYTES = (MODE == 1) ? AttnLdsH<1, 1, 1>::BYTES : AttnLds<1>::BYTES;
+    __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+    float* lds = reinterpret_cast<float*>(lds_raw);
+    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
+    asm volatile("" : "+s"(one));
     const int b = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int k = M.k, nb = S2S_T_ENC + k - 1;
     const uint8_t* bp = bases + (size_t)b * nb;
@@ -77,9 +87,15 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
 #pragma unroll 1
     for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
         f32x4 Y[1][4];
+        if (MODE == 1) {
+            HL xb[1][2];
+            xb[0][0] = split8(X[0][0], X[0][1], one); xb[0][1] = split8(X[0][2], X[0][3], one);
+            linear64_h(W + M.pre_wh[i], W + M.pre_b[i], lane, xb, Y);
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) Y[0][mt] = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
-        gemm_acc<1, 4, 4>(W + M.pre_w[i], lane, Y, X);
+            for (int mt = 0; mt < 4; ++mt) Y[0][mt] = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
+            gemm_acc<1, 4, 4>(W + M.pre_w[i], lane, Y, X);
+        }
         relu_tiles<4>(Y);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) X[0][mt] = Y[0][mt];
@@ -96,7 +112,12 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
             *reinterpret_cast<f32x4*>(dbg.emb_out + ((dbg_base + b) * 16 + c) * 64 + 16 * ft + 4 * g) = S[0][ft];
     }
 #pragma unroll 1
-    for (int l = 0; l < M.enc_layers; ++l) fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane);
+    for (int l = 0; l < M.enc_layers; ++l) {
+        if (MODE == 1) fft_block_h<1, 1, 1, 16>(W, M.enc[l], X, lds_raw, 0, 0, lane, one);
+        else           fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane);
+    }
+    HL Sb[1][2];                                                     // emb_out as a B operand for the three heads
+    if (MODE == 1) { Sb[0][0] = split8(S[0][0], S[0][1], one); Sb[0][1] = split8(S[0][2], S[0][3], one); }
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft)
         *reinterpret_cast<f32x4*>(ws_enc + ((size_t)b * 16 + c) * 64 + 16 * ft + 4 * g) = X[0][ft];
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
     }
 
     // ---- NoiseSampler (modules.py:275-278)
-    const float sigma = mlp_head(W, M.noise, S, lane);
+    const float sigma = mlp_head<MODE>(W, M.noise, S, Sb, lane);
     if (g == 0) {
         ws_sigma[b * 16 + c] = sigma;
         if (dbg.sigma) dbg.sigma[(dbg_base + b) * 16 + c] = sigma;
@@ -115,8 +136,8 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
     // ---- dwell source (modules.py:396-438)
     float gv;
     if (P.duration_sampling) {
-        const float conc = fmaxf(mlp_head(W, M.conc, S, lane), 1e-8f);      // modules.py:215-216
-        const float rate = fmaxf(mlp_head(W, M.rate, S, lane), 1e-8f);      // modules.py:217-218
+        const float conc = fmaxf(mlp_head<MODE>(W, M.conc, S, Sb, lane), 1e-8f);      // modules.py:215-216
+        const float rate = fmaxf(mlp_head<MODE>(W, M.rate, S, Sb, lane), 1e-8f);      // modules.py:217-218
         if (g == 0) {
             if (dbg.conc) dbg.conc[(dbg_base + b) * 16 + c] = conc;
             if (dbg.rate) dbg.rate[(dbg_base + b) * 16 + c] = rate;
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
 #define DEC_NQ 2            // 16-column time tiles per wave: 8 waves x 2 x 16 = 256 >= 250
 #define DEC_NKT 16
 static constexpr int DEC_LDS_F32 = AttnLds<DEC_NKT>::BYTES;
-static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES>::BYTES;
+static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>::BYTES;
 
 template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h)
 __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     DIAG_STAMP(8);
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
-        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
+        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
         else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
     }
 
@@ -511,11 +532,31 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     return L;
 }
 
+// a 64x64 Linear as 4 f16 units (one per m-tile): [kb0 hi][kb0 lo][kb1 hi][kb1 lo], same fragment order as pack_layer
+int pack_linear64_h(Arena& A, const float* Wm) {
+    std::vector<_Float16> sh;
+    for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < 2; ++kb)
+            for (int lo = 0; lo < 2; ++lo)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, i = lane & 15;
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = Wm[(size_t)(16 * mt + i) * 64 + 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3)];
+                        const _Float16 hi = (_Float16)w;
+                        sh.push_back(lo ? (_Float16)(w - (float)hi) : hi);
+                    }
+                }
+    std::vector<float> raw(sh.size() / 2);
+    std::memcpy(raw.data(), sh.data(), sh.size() * sizeof(_Float16));
+    return A.put(raw.data(), raw.size());
+}
+
 MlpOff pack_mlp(Arena& A, const float*& p) {
     MlpOff m;
     const float* w0 = take(p, 4096); const float* b0 = take(p, 64);
     const float* w3 = take(p, 64);   const float* b3 = take(p, 1);
     m.w0 = A.put_afrag(w0, 64, 64, false); m.b0 = A.put(b0, 64);
+    m.w0h = pack_linear64_h(A, w0);
     m.w3 = A.put(w3, 64); m.b3 = A.put(b3, 1);
     return m;
 }
@@ -580,6 +621,7 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     for (int i = 0; i < cfg->pre_layers; ++i) {
         const float* w = take(p, 4096);
         M.pre_w[i] = A.put_afrag(w, 64, 64, false);
+        M.pre_wh[i] = pack_linear64_h(A, w);
         M.pre_b[i] = A.put(take(p, 64), 64);
     }
     for (int l = 0; l < cfg->encoder_layers; ++l) M.enc[l] = pack_layer(A, p);
@@ -656,9 +698,14 @@ int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const
     const int nb = S2S_T_ENC + h->cfg.seq_kmer - 1;
     for (int64_t s = 0; s < B; s += h->tile) {
         const int n = (int)((B - s < h->tile) ? (B - s) : h->tile);
-        hipLaunchKernelGGL(s2s_frontend_kernel, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, bases + (size_t)s * nb,
-                           n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
-                           inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
+        if (h->cfg.compute_mode == S2S_MODE_F16X3)
+            hipLaunchKernelGGL(s2s_frontend_kernel<1>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, bases + (size_t)s * nb,
+                               n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
+                               inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
+        else
+            hipLaunchKernelGGL(s2s_frontend_kernel<0>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, bases + (size_t)s * nb,
+                               n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
+                               inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
         EventPair ev{};
         if (h->profiling) {
             HIP_TRY(h, hipEventCreate(&ev.a));

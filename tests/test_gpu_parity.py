@@ -44,17 +44,21 @@ def dev_t(case, key):
 
 
 def test_stage_outputs(case):
+    """Intermediate tensors against the reference's (scaled units).  The split-f16 arithmetic carries 22-bit
+    operands, so its stage tolerances are a few 1e-6 wider than the exact-fp32 path's."""
     g, eng = case["g"], case["eng"]
+    t = dict(emb=2e-6, enc=2e-5, sig=2e-6, rel=2e-6, y=2e-5) if eng.mode == "f32" else \
+        dict(emb=1e-5, enc=6e-5, sig=1e-5, rel=3e-5, y=6e-5)
     out = eng.predict_chunks(case["bases"], case["nv"], S.PredictParams(**P(noise_std=0.0)),
                              inject_g=dev_t(case, "g"), debug=True)
     torch.cuda.synchronize()
-    assert np.abs(out["emb_out"].cpu().numpy() - g["emb_out"]).max() < 2e-6
-    assert np.abs(out["enc_out"].cpu().numpy() - g["enc_out"]).max() < 2e-5
-    assert np.abs(out["sigma"].cpu().numpy() - g["sigma"]).max() < 2e-6
-    assert np.allclose(out["conc"].cpu().numpy(), g["conc"], rtol=2e-6, atol=2e-6)
-    assert np.allclose(out["rate"].cpu().numpy(), g["rate"], rtol=2e-6, atol=2e-6)
+    assert np.abs(out["emb_out"].cpu().numpy() - g["emb_out"]).max() < t["emb"]
+    assert np.abs(out["enc_out"].cpu().numpy() - g["enc_out"]).max() < t["enc"]
+    assert np.abs(out["sigma"].cpu().numpy() - g["sigma"]).max() < t["sig"]
+    assert np.allclose(out["conc"].cpu().numpy(), g["conc"], rtol=t["rel"], atol=t["rel"])
+    assert np.allclose(out["rate"].cpu().numpy(), g["rate"], rtol=t["rel"], atol=t["rel"])
     assert np.array_equal(out["dur"].cpu().numpy(), g["dur_gamma"])
-    assert np.abs(out["y_scaled"].cpu().numpy() - g["y_scaled_gamma"]).max() < 2e-5
+    assert np.abs(out["y_scaled"].cpu().numpy() - g["y_scaled_gamma"]).max() < t["y"]
 
 
 CASES = [
