@@ -370,10 +370,17 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         }
     }
     DIAG_STAMP(3);
-    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
-    DIAG_STAMP(4);
 
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
+    // A weight unit feeds only 6*NQ MFMAs (~200 cycles) here, less than an L2 round trip, so the stream
+    // runs three units ahead through a ring of four unit buffers (8 units per slice: slots repeat).
+    f32x4 ring[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
+    load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); ws += 2048;
+    __builtin_amdgcn_sched_barrier(0);
+    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+    DIAG_STAMP(4);
     HL x1b[NQ][2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1], one); x1b[q][1] = split8(acc[q][2], acc[q][3], one); }
@@ -393,25 +400,27 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int mt = 0; mt < 4; ++mt) {              // W1 units: rows 64hc + 16mt ..
             f32x4 t[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) t[q] = b1[mt];
-            if (mt & 1) { load_unit(fa, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fb, x1b); }
-            else        { load_unit(fb, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fa, x1b); }
+            for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
+            load_unit(ring[(mt + 3) & 3], ws); ws += 1024;
+            __builtin_amdgcn_sched_barrier(0);
+            mm_unit_h<NQ>(t, ring[mt & 3], x1b);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r] + b1[mt][r], 0.0f);
         }
         HL hb[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1], one); hb[q][1] = split8(hid[q][2], hid[q][3], one); }
-    #pragma unroll
+#pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
-            if (mt & 1) { load_unit(fa, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fb, hb); }
-            else        { load_unit(fb, ws); ws += 1024; __builtin_amdgcn_sched_barrier(0); mm_unit_h<NQ>(t, fa, hb); }
+            load_unit(ring[(mt + 3) & 3], ws); ws += 1024;
+            __builtin_amdgcn_sched_barrier(0);
+            mm_unit_h<NQ>(t, ring[mt & 3], hb);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];

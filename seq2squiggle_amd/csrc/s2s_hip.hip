@@ -513,7 +513,7 @@ LayerOff pack_layer(Arena& A, const float*& p) {
         for (int mt = 0; mt < 4; ++mt) unit_h(w1, 64, 4 * hc + mt, 0);
         for (int mt = 0; mt < 4; ++mt) unit_h(w2, 256, mt, 64 * hc);
     }
-    sh.resize(sh.size() + 2048, (_Float16)0.0f);
+    sh.resize(sh.size() + 4 * 2048, (_Float16)0.0f);   // the FFN ring runs three units past the end of the stream
     {
         std::vector<float> raw(sh.size() / 2);
         std::memcpy(raw.data(), sh.data(), sh.size() * sizeof(_Float16));
