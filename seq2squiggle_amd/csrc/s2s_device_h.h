@@ -128,7 +128,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                                             unsigned long long* diag_buf = nullptr) {
     using G = AttnLdsH<NQ, WAVES, NKT>;
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
-    constexpr float THR = 8.0f;                                  // deferred-max threshold (log2 units)
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
@@ -228,6 +227,16 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ], negm[NQ];
                 float m[NQ];
+                // Online softmax over NH passes of HK key tiles.  Pass 0 subtracts its own column max; later
+                // passes get "score - m" straight out of the MFMA (the accumulator starts at -m).
+                //   attempt 0 (fast): m stays the pass-0 max and later passes compute no max at all.  Softmax is
+                //     shift-invariant, so this is exact as long as no later score beats m by 2^16 (f16 range of
+                //     P_hi); if one does, the row sum turns inf/NaN, which is checked once per head, and
+                //   attempt 1 (safe, rare): the head is redone with the running max raised, and the sums
+                //     rescaled, in every pass.
+#pragma unroll 1
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool safe = (attempt != 0) || S2S_ALWAYS_RESCALE;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
@@ -235,11 +244,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     negm[q] = f32x4{0, 0, 0, 0};
                     m[q] = 0.0f;
                 }
-                // Online softmax over NH passes.  Pass 0 subtracts its own column max.  Later passes get
-                // "score - running max" straight out of the MFMA (the accumulator starts at -m), and the
-                // running max is only raised -- with the accumulators rescaled -- when some column of the
-                // wave exceeds it by more than THR (p <= 2^THR otherwise): softmax is shift-invariant, so
-                // this changes rounding only.
 #pragma unroll
                 for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
                     h8 ka[HK], va[HB];
@@ -261,45 +265,38 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt)
                             s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
-                    // per-lane partial maxima; the cross-lane reduction is only needed in pass 0 and on the
-                    // (rare) raise path -- the raise test itself is a wave-wide vote on the partial maxima
-                    float mh[NQ];
-                    bool raise = false;
+                    if (TV < 16 * NKT && h2 == NH - 1) {       // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        if (TV < 16 * NKT && h2 == NH - 1) {   // phantom keys -> -inf (only the last key tile has any)
+                        for (int q = 0; q < NQ; ++q)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 if (16 * (NKT - 1) + 4 * g + r >= TV) s[q][HK - 1][r] = -__builtin_inff();
-                        }
-                        mh[q] = s[q][0][0];
-                        if (!(S2S_ABL & 32)) {
-#pragma unroll
-                            for (int kt = 0; kt < HK; ++kt)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) mh[q] = fmaxf(mh[q], s[q][kt][r]);
-                        }
-                        raise = raise || (mh[q] > THR);
                     }
-                    if (h2 == 0) {
+                    if (h2 == 0 || safe) {
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) {
-                            const float gm = (S2S_ABL & 32) ? mh[q] : max_g(mh[q]);
-                            m[q] = gm;
-                            negm[q] = f32x4{-gm, -gm, -gm, -gm};
+                            float mh = s[q][0][0];
+                            if (!(S2S_ABL & 32)) {
 #pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) s[q][kt] -= gm;
-                        }
-                    } else if (S2S_ALWAYS_RESCALE || (!(S2S_ABL & 32) && __any(raise))) {   // rare: raise the running max
+                                for (int kt = 0; kt < HK; ++kt)
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const float delta = fmaxf(max_g(mh[q]), 0.0f);
-                            const float alpha = __builtin_amdgcn_exp2f(-delta);
-                            oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
-                            m[q] += delta;
-                            negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
+                                    for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[q][kt][r]);
+                                mh = max_g(mh);
+                            }
+                            if (h2 == 0) {
+                                m[q] = mh;
+                                negm[q] = f32x4{-mh, -mh, -mh, -mh};
 #pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) s[q][kt] -= delta;
+                                for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
+                            } else {                              // safe attempt: raise the running max, rescale the sums
+                                const float delta = fmaxf(mh, 0.0f);
+                                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                                oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
+                                m[q] += delta;
+                                negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
+#pragma unroll
+                                for (int kt = 0; kt < HK; ++kt) s[q][kt] -= delta;
+                            }
                         }
                     }
                     HL P[NQ][HB];
@@ -324,6 +321,15 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                             }
                         }
                     }
+                }
+                if (safe) break;
+                bool bad = false;                              // inf or NaN row sum: some P_hi left the f16 range
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + lL[q][0] <= 3.0e38f);
+#ifdef S2S_NO_FALLBACK       // test-only build: proves that tests/test_gpu_parity.py::test_peaked_attention... needs the fallback
+                break;
+#endif
+                if (!__any(bad)) break;
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {

@@ -183,11 +183,14 @@ static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>::BYTES;
 template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h)
 __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
     const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
-    const float* __restrict__ ws_sigma, const int* __restrict__ dur, long long first_chunk, ParamsDev P,
+    const float* __restrict__ ws_sigma, const int* __restrict__ dur, int n_chunks, long long first_chunk, ParamsDev P,
     const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float* lds = reinterpret_cast<float*>(lds_raw);
-    const int b = blockIdx.x;
+    // persistent workgroups (LDS allows one per CU): each walks the chunk list with stride gridDim.x, so a CU
+    // never waits for a workgroup to drain, be re-dispatched and re-allocate 148 KB of LDS between chunks
+#pragma unroll 1
+    for (int b = blockIdx.x; b < n_chunks; b += gridDim.x) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int qt0 = DEC_NQ * wave;
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
         }
     }
     DIAG_STAMP(9);
+    }   // chunk loop
 }
 
 // ================================================================================ export
@@ -372,6 +376,7 @@ struct s2s_handle {
     float* d_arena = nullptr;
     size_t arena_floats = 0;
     int tile = 0;                     // chunks per launch pair
+    int n_wg = 256;                   // decoder grid: persistent workgroups, one per CU
     float* ws_enc = nullptr;          // [tile][16][64]
     float* ws_sigma = nullptr;        // [tile][16]
     int* ws_counts = nullptr;         // export scratch, grown on demand outside of launches
@@ -602,6 +607,7 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     s2s_handle* h = new s2s_handle();
     h->cfg = *cfg;
     h->device = device;
+    h->n_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int k = cfg->seq_kmer;
     Arena A;
     ModelDev& M = h->model;
@@ -713,13 +719,13 @@ int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const
             HIP_TRY(h, hipEventRecord(ev.a, stream));
         }
         if (h->cfg.compute_mode == S2S_MODE_F16X3)
-            hipLaunchKernelGGL(s2s_decoder_kernel<1>, dim3(n), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
-                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, (long long)(first_global_chunk + s),
+            hipLaunchKernelGGL(s2s_decoder_kernel<1>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
+                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
                                P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
                                (long long)s);
         else
-            hipLaunchKernelGGL(s2s_decoder_kernel<0>, dim3(n), dim3(DEC_WAVES * 64), AttnLds<DEC_NKT>::BYTES, stream, h->model,
-                               h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, (long long)(first_global_chunk + s), P,
+            hipLaunchKernelGGL(s2s_decoder_kernel<0>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), AttnLds<DEC_NKT>::BYTES, stream, h->model,
+                               h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s), P,
                                inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
                                (long long)s);
         if (h->profiling) {
