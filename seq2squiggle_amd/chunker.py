@@ -69,3 +69,23 @@ def codes_to_bases(codes: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         if nv:
             bases[b, nv - 1: nv - 1 + k] = lut[codes[b, nv - 1]]
     return bases, n_valid
+
+
+def pack_reads(seqs: Sequence[str], k: int):
+    """Flat form for device-side chunking: -> (flat uint8 bytes with every read padded by "_" to 16*C + k - 1,
+    chunk_start int64 [C_total] into flat, n_valid uint8 [C_total], read_first int32 [R+1]).  Chunk b is
+    flat[chunk_start[b] : chunk_start[b] + 16 + k - 1]: one gather on the GPU replaces the per-read window copies."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    n_kmer = np.maximum(lens - k + 1, 0)
+    C = -(-n_kmer // T_ENC)
+    padded = np.where(C > 0, T_ENC * C + k - 1, 0)
+    base = np.concatenate([[0], np.cumsum(padded)])
+    flat = np.full(int(base[-1]) + 1, ord("_"), dtype=np.uint8)
+    for i, s_ in enumerate(seqs):
+        if C[i] > 0:
+            flat[base[i]: base[i] + lens[i]] = np.frombuffer(s_.encode("latin-1"), dtype=np.uint8)
+    read_first = np.concatenate([[0], np.cumsum(C)]).astype(np.int32)
+    within = np.arange(int(read_first[-1])) - np.repeat(read_first[:-1], C)          # chunk index inside its read
+    chunk_start = np.repeat(base[:-1], C) + T_ENC * within
+    n_valid = np.minimum(T_ENC, np.repeat(n_kmer, C) - T_ENC * within).astype(np.uint8)
+    return flat, chunk_start.astype(np.int64), n_valid, read_first

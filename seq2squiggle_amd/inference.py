@@ -8,7 +8,7 @@ from typing import Iterable, Iterator, Tuple
 import numpy as np
 import torch
 
-from .chunker import encode_read
+from .chunker import encode_read, n_chunks as _n_chunks, pack_reads
 from .model import seq2squiggle
 from .parallel import rank_output_path, rank_world, shard_reads
 from .signal_io import BLOW5Writer, POD5Writer
@@ -77,13 +77,63 @@ def iter_batches(reads: Iterable[Tuple[str, str]], k: int, batch_size: int, devi
         yield tuple(ids), torch.from_numpy(np.concatenate(parts)).to(device), torch.from_numpy(np.concatenate(nvs)).to(device)
 
 
+def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
+                  max_chunks: int = 32768) -> int:
+    """The predict loop without per-chunk Python objects: whole reads are grouped into super-batches of about
+    `max_chunks` chunks; per super-batch one H2D of the read bytes, a gather into chunk windows, s2s_predict_chunks,
+    s2s_export_reads (zero-strip + int16 conversion on the GPU), one D2H of the packed int16 samples, then the
+    writer.  Produces the same records as predict_step + export_and_clear_results + writer.save()."""
+    k = model.config["seq_kmer"]
+    nb = 16 + k - 1
+    dev = model.device
+    rna = profile_name.startswith("rna")
+    win = torch.arange(nb, device=dev)
+    total = 0
+
+    def flush(group):
+        nonlocal total
+        ids = [n for _, n in group]
+        flat, chunk_start, n_valid, read_first = pack_reads([s for s, _ in group], k)
+        B = int(read_first[-1])
+        if B == 0:
+            return
+        flat_d = torch.from_numpy(flat).to(dev, non_blocking=True)
+        bases = flat_d[torch.from_numpy(chunk_start).to(dev).unsqueeze(1) + win]           # [B, nb] gather
+        out = model.engine.predict_chunks(bases.contiguous(), torch.from_numpy(n_valid).to(dev), model._params(),
+                                          first_global_chunk=model.chunks_done)
+        model.chunks_done += B
+        ex = model.engine.export_reads(out["signal"], torch.from_numpy(read_first).to(dev), profile_dict["digitisation"],
+                                       profile_dict["range"], profile_dict["offset_mean"], rna=rna, want_pa=False,
+                                       want_dac=True)
+        offs = ex["offsets"].cpu().numpy()
+        dac = ex["dac"][: int(offs[-1])].cpu().numpy()
+        writer.save_dac(ids, dac, offs)
+        total += B
+
+    group, n = [], 0
+    for seq, name in reads:
+        c = _n_chunks(len(seq), k)
+        if c == 0:
+            logger.debug(f"Skipped read {name}.")
+            continue
+        group.append((seq, name))
+        n += c
+        if n >= max_chunks:
+            flush(group)
+            group, n = [], 0
+    if group:
+        flush(group)
+    return total
+
+
 def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool, n: int, r: int, c: int, out: str,
                   profile: dict, dwell_mean: int, dwell_std: float, noise_std: float, noise_sampling: bool,
                   duration_sampling: bool, distr: str, predict_batch_size: int, export_every_n_samples: int,
                   sample_rate: int, bps: int, digitisation: int, range_val: float, offset_mean: float, offset_std: float,
                   median_before_mean: float, median_before_std: float, min_noise: float, min_duration: float,
-                  min_read_len: int, preserve_read_ids: bool, seed: int, mode: str = "f16x3"):
-    """Same 30 parameters as the reference (inference.py:270-301) plus `mode` (decoder arithmetic)."""
+                  min_read_len: int, preserve_read_ids: bool, seed: int, mode: str = "f16x3", streaming: bool = True):
+    """Same 30 parameters as the reference (inference.py:270-301) plus `mode` (decoder arithmetic) and `streaming`
+    (True: run_streaming; False: the reference's predict_step / export_and_clear_results flow, batch by batch)."""
     profile_dict = get_profile(profile)
     profile_dict = update_profile(profile_dict, sample_rate=sample_rate, bps=bps, digitisation=digitisation, range=range_val,
                                   offset_mean=offset_mean, offset_std=offset_std, median_before_mean=median_before_mean,
@@ -116,10 +166,13 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     check_model(load_model, config)
 
     n_chunks = 0
-    for batch in iter_batches(reads, config["seq_kmer"], predict_batch_size, load_model.device):
-        load_model.predict_step(batch)
-        n_chunks += len(batch[0])
-    load_model.on_predict_epoch_end()
+    if streaming and isinstance(writer, BLOW5Writer):
+        n_chunks = run_streaming(load_model, reads, writer, profile_dict, profile)
+    else:
+        for batch in iter_batches(reads, config["seq_kmer"], predict_batch_size, load_model.device):
+            load_model.predict_step(batch)
+            n_chunks += len(batch[0])
+        load_model.on_predict_epoch_end()
     torch.cuda.synchronize(load_model.device)
     logger.info(f"Predicted {n_chunks} chunks ({n_chunks * 250} padded samples).")
     return load_model

@@ -113,47 +113,61 @@ class BLOW5Writer:
         return "\n".join(lines) + "\n"
 
     # ------------------------------------------------------------------ records
+    def _record(self, read_id, raw):
+        """One record as the reference builds it (signal_io.py:123-161)."""
+        if self.ideal_mode:
+            median_before_value, offset_value = self.median_before, self.offset
+        else:
+            median_before_value = np.random.normal(self.median_before, self.median_before_std)
+            offset_value = np.random.normal(self.offset, self.offset_std)
+        self.n_written += 1
+        rid = read_id if self.preserve_read_ids else indexed_uuid(self.n_written)
+        rec = {"read_id": str(rid), "read_group": 0, "digitisation": self.digitisation, "offset": offset_value,
+               "range": self.signal_range, "sampling_rate": self.sample_rate, "len_raw_signal": len(raw),
+               "signal": raw, "channel_number": "0", "median_before": median_before_value,
+               "read_number": self.n_written - 1, "start_mux": 0, "start_time": self.start_time}
+        self.start_time += len(raw)
+        return rec
+
     def records(self):
-        """The records of the current `signals`, as the reference builds them (signal_io.py:123-161)."""
+        """The records of the current `signals` (pA tensors; converted here like signal_io.py:134-141)."""
         rna = self.profile_name.startswith("rna")
         for read_id, signal in self.signals.items():
             if len(signal) == 0:
                 logger.debug("Empty signal, skipping {}".format(read_id))
                 continue
-            if self.ideal_mode:
-                median_before_value, offset_value = self.median_before, self.offset
-            else:
-                median_before_value = np.random.normal(self.median_before, self.median_before_std)
-                offset_value = np.random.normal(self.offset, self.offset_std)
             if self.dac is not None and read_id in self.dac:
                 raw = np.asarray(self.dac[read_id], dtype=np.int16)
             else:
                 sig = signal.detach().cpu().numpy() if hasattr(signal, "detach") else np.asarray(signal)
                 raw = signal_to_dac(sig, self.digitisation, self.signal_range, self.offset, rna)
-            self.n_written += 1
-            rid = read_id if self.preserve_read_ids else indexed_uuid(self.n_written)
-            rec = {"read_id": str(rid), "read_group": 0, "digitisation": self.digitisation, "offset": offset_value,
-                   "range": self.signal_range, "sampling_rate": self.sample_rate, "len_raw_signal": len(raw),
-                   "signal": raw, "channel_number": "0", "median_before": median_before_value,
-                   "read_number": self.n_written - 1, "start_mux": 0, "start_time": self.start_time}
-            self.start_time += len(raw)
-            yield rec
+            yield self._record(read_id, raw)
+
+    def save_dac(self, read_ids, dac: np.ndarray, offsets: np.ndarray):
+        """Streaming path: samples already converted to int16 on the GPU (s2s_export_reads), packed read after read;
+        read r is dac[offsets[r]:offsets[r+1]].  Same records and append semantics as save()."""
+        recs = (self._record(rid, dac[offsets[i]:offsets[i + 1]]) for i, rid in enumerate(read_ids)
+                if offsets[i + 1] > offsets[i])
+        self._write(recs)
 
     def save(self):
         if self.signals is None:
             logger.warning("SLOW5 was not exported. No signals were found")
             raise ValueError("SLOW5 was not exported. No signals were found")
+        self._write(self.records())
+
+    def _write(self, recs):
         append = os.path.exists(self.filename)
         if self.binary:
-            self._save_blow5(append)
+            self._save_blow5(append, recs)
         else:
-            self._save_slow5(append)
+            self._save_slow5(append, recs)
 
-    def _save_slow5(self, append: bool):
+    def _save_slow5(self, append: bool, recs):
         with open(self.filename, "a" if append else "w") as f:
             if not append:
                 f.write(self._header_text())
-            for r in self.records():
+            for r in recs:
                 f.write("\t".join([r["read_id"], str(r["read_group"]), _fmt_double(r["digitisation"]),
                                    _fmt_double(r["offset"]), _fmt_double(r["range"]), _fmt_double(r["sampling_rate"]),
                                    str(r["len_raw_signal"]), ",".join(map(str, r["signal"].tolist())),
@@ -163,7 +177,18 @@ class BLOW5Writer:
     # BLOW5 v0.2.0: 64-byte file header, u32 size + ASCII header, records (u64 size + zlib stream), "5WOLB"
     _EOF = b"5WOLB"
 
-    def _save_blow5(self, append: bool):
+    @staticmethod
+    def _blow5_record(r) -> bytes:
+        rid, ch = r["read_id"].encode(), r["channel_number"].encode()
+        body = (struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", r["read_group"], r["digitisation"], r["offset"],
+                                                                 r["range"], r["sampling_rate"], r["len_raw_signal"])
+                + np.ascontiguousarray(r["signal"]).astype("<i2").tobytes()
+                + struct.pack("<H", len(ch)) + ch
+                + struct.pack("<diBQ", r["median_before"], r["read_number"], r["start_mux"], r["start_time"]))
+        z = zlib.compress(body)
+        return struct.pack("<Q", len(z)) + z
+
+    def _save_blow5(self, append: bool, recs):
         if append:
             with open(self.filename, "r+b") as f:      # drop the end-of-file marker, then append
                 f.seek(-len(self._EOF), os.SEEK_END)
@@ -176,16 +201,12 @@ class BLOW5Writer:
                 fh = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1]) + struct.pack("<I", 1) + bytes([0])
                 f.write(fh + bytes(64 - len(fh)))
                 f.write(struct.pack("<I", len(hdr)) + hdr)
-            for r in self.records():
-                rid, ch = r["read_id"].encode(), r["channel_number"].encode()
-                body = (struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", r["read_group"], r["digitisation"],
-                                                                          r["offset"], r["range"], r["sampling_rate"],
-                                                                          r["len_raw_signal"])
-                        + r["signal"].astype("<i2").tobytes()
-                        + struct.pack("<H", len(ch)) + ch
-                        + struct.pack("<diBQ", r["median_before"], r["read_number"], r["start_mux"], r["start_time"]))
-                z = zlib.compress(body)
-                f.write(struct.pack("<Q", len(z)) + z)
+            # zlib releases the GIL: compress records on worker threads, write in order
+            # (the reference: write_record_batch(threads=cpu_count), signal_io.py:167-171)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
+                for blob in pool.map(self._blow5_record, recs):
+                    f.write(blob)
             f.write(self._EOF)
 
 

@@ -66,6 +66,34 @@ def test_model_object_export_flow(tmp_path, mode, tag, profile_name):
     check_file(tmp_path / "o.blow5", exp, [n for _, n in reads])
 
 
+@pytest.mark.parametrize("ext", [".blow5", ".slow5"])
+def test_streaming_path_equals_predict_step_path(tmp_path, ext):
+    """run_streaming (GPU zero-strip + DAC, no per-chunk Python objects) writes the same file content as the
+    reference-shaped predict_step / export_and_clear_results / writer.save() flow, samplers on, fixed seed."""
+    from seq2squiggle_amd.cli import set_config
+    outs = []
+    rng = np.random.default_rng(1)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for i, n in enumerate([5, 9, 40, 333, 1200, 16 + 8, 2500]):
+            f.write(f">r{i}\n{''.join(rng.choice(list('ACGT'), n))}\n")
+    for streaming in (True, False):
+        out = tmp_path / f"s{int(streaming)}{ext}"
+        np.random.seed(0)
+        inference_run(config=set_config(None), saved_weights=os.path.join(GOLDEN, "synthetic_k9.ckpt"), fasta=str(fa),
+                      read_input=True, n=-1, r=1000, c=-1, out=str(out), profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0,
+                      noise_std=2.0, noise_sampling=True, duration_sampling=True, distr="expon", predict_batch_size=64,
+                      export_every_n_samples=100, sample_rate=None, bps=None, digitisation=None, range_val=None,
+                      offset_mean=None, offset_std=None, median_before_mean=None, median_before_std=None, min_noise=0.0,
+                      min_duration=3, min_read_len=30, preserve_read_ids=True, seed=11, streaming=streaming)
+        outs.append((signal_io.read_slow5 if ext == ".slow5" else signal_io.read_blow5)(str(out))[1])
+    a, b = outs
+    assert [r["read_id"] for r in a] == [r["read_id"] for r in b] == ["r1", "r2", "r3", "r4", "r5", "r6"]
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["signal"], rb["signal"])
+        assert ra["start_time"] == rb["start_time"] and ra["len_raw_signal"] == rb["len_raw_signal"]
+
+
 def test_reference_style_onehot_batch(tmp_path):
     """predict_step also accepts the reference's own batch format (tuple[str], fp16 one-hot [B,16,k,5])."""
     g = load_npz("stages_k9.npz")
