@@ -248,3 +248,37 @@ def test_export_zero_strip_and_dac(case):
     dr = exr["dac"].cpu().numpy()
     for r in range(len(order)):
         assert np.array_equal(dr[offs[r]:offs[r + 1]], dac[offs[r]:offs[r + 1]][::-1])
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] size (1000 reads x 5 kb = 312,000 chunks, 10 launch tiles): size-independent
+    properties the domain offers -- determinism (same seed -> identical samples), tile/batch invariance of the
+    counter-based RNG (any split of the batch gives the same chunks) and the strip/offset bookkeeping of the export."""
+    sd, cfg = load_ckpt("k9")
+    eng = S.Engine(sd, cfg, mode="f16x3")
+    rng = np.random.default_rng(1234)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [lut[rng.integers(0, 4, 5000)].tobytes().decode() for _ in range(1000)]
+    bases, nv, first = S.encode_reads(reads, 9)
+    assert bases.shape[0] == 312000
+    b, n = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda()
+    pp = S.PredictParams(seed=42)
+    a = eng.predict_chunks(b, n, pp)
+    a_sig, a_dur = a["signal"].clone(), a["dur"].clone()
+    again = eng.predict_chunks(b, n, pp)
+    assert torch.equal(a_sig, again["signal"]) and torch.equal(a_dur, again["dur"])
+    cut = 100003                                               # not a multiple of the 32,768-chunk launch tile
+    lo = eng.predict_chunks(b[:cut].contiguous(), n[:cut].contiguous(), pp)
+    hi = eng.predict_chunks(b[cut:].contiguous(), n[cut:].contiguous(), pp, first_global_chunk=cut)
+    assert torch.equal(a_sig, torch.cat([lo["signal"], hi["signal"]])) and torch.equal(a_dur, torch.cat([lo["dur"], hi["dur"]]))
+    assert torch.isfinite(a_sig).all() and (a_sig >= 0).all() and (a_dur >= 3).all()
+    # (rows past sum(dur) are NOT forced to zero: as in the reference, the decoder sees zero rows + position_enc
+    # there and only samples its ReLU/clamp zeroes are stripped, model.py:284-286)
+    nz = (a_sig != 0).sum(1)
+    ex = eng.export_reads(a_sig, torch.from_numpy(first).cuda(), 2048.0, 281.345551, -127.5655735, want_pa=True, want_dac=True)
+    offs = ex["offsets"].cpu().numpy()
+    per_read = nz.cpu().numpy().reshape(1000, 312).sum(1)
+    assert np.array_equal(np.diff(offs), per_read) and offs[-1] == int(nz.sum())
+    pa = ex["pa"][: offs[-1]]
+    assert (pa != 0).all() and torch.equal(pa, a_sig[a_sig != 0])        # compaction keeps order and values
+    eng.close()
