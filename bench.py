@@ -30,7 +30,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4
 PEAK_F16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 # f16x3 evaluates every algorithmic product as three f16 MFMA products (hi*hi + hi*lo + lo*hi), so
 # the matrix-core ceiling for ALGORITHMIC flops is a third of the dense f16 peak.
-PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0}
+PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f16x3w": PEAK_F16_MFMA_TFLOPS / 3.0}
 READ_LEN, CHUNKS_PER_READ = 5000, 312
 
 
@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3"],
+    ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3", "f16x3w"],
                     help="decoder arithmetic: f32-input MFMA, or split-f16 (3 f16 MFMA products, fp32 accumulate)")
     a = ap.parse_args()
 

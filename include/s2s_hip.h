@@ -34,6 +34,7 @@ extern "C" {
  *                   fp32 accumulation per original product (v_mfma_f32_16x16x32_f16). */
 #define S2S_MODE_F32 0
 #define S2S_MODE_F16X3 1
+#define S2S_MODE_F16X3W 2   /* same arithmetic as F16X3, decoder tiled for v_mfma_f32_32x32x16_f16 */
 
 #define S2S_T_ENC 16         /* config.yaml:18 max_dna_len    */
 #define S2S_T_DEC 250        /* config.yaml:19 max_signal_len */
