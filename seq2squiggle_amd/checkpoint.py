@@ -56,7 +56,7 @@ def state_dict_to_blob(sd: Dict[str, torch.Tensor], cfg: dict) -> np.ndarray:
 MODES = {"f32": 0, "f16x3": 1, "f16x3w": 2}
 
 
-def config_to_c(cfg: dict, mode: str = "f32") -> S2SConfig:
+def config_to_c(cfg: dict, mode: str = "f16x3") -> S2SConfig:
     if cfg["encoder_heads"] != cfg["decoder_heads"]:
         raise ValueError("encoder_heads != decoder_heads is not supported")
     if mode not in MODES:

@@ -127,10 +127,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr) {
     using G = AttnLdsH<NQ, WAVES, NKT>;
-#ifndef S2S_H_PASSES
-#define S2S_H_PASSES 4
-#endif
-    constexpr int NH = (NKT >= 16) ? S2S_H_PASSES : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: passes of 64 or 32
+    constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
@@ -218,6 +215,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 0) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = hi;
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 1) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
+            // (indexed by the lane-dependent select below, so hipcc keeps it in scratch: a deliberate parking spot -- every
+            //  register-resident formulation tried pushed the kernel over 256 VGPRs and spilled hot values instead)
             f32x4 ohead[2][NQ];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -228,149 +227,111 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     qb[q] = *reinterpret_cast<const h8*>(Ql + (((q * 2 + (g & 1)) * 2 + hh) * 16 + c) * 8);
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
-                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
-                // Online softmax over NH passes of HK key tiles.
-                //   fast attempt: pass 0 subtracts its own column max m; later passes get "score - m" straight out
-                //     of the MFMA (accumulator initialised to -m) and compute no max at all.  Softmax is
-                //     shift-invariant, so this is exact unless a later score beats m by 2^16 (f16 range of P_hi);
-                //     then the row sum turns inf/NaN, which is checked once per head.  The QK^T MFMAs of pass
-                //     h2+1 are issued before the exponentials of pass h2, so the matrix core and the LDS reads
-                //     run under the VALU work.
-                //   safe attempt (rare): the head is redone with the running max raised, and the sums
+                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ], negm[NQ];
+                float m[NQ];
+                // Online softmax over NH passes of HK key tiles.  Pass 0 subtracts its own column max; later
+                // passes get "score - m" straight out of the MFMA (the accumulator starts at -m).
+                //   attempt 0 (fast): m stays the pass-0 max and later passes compute no max at all.  Softmax is
+                //     shift-invariant, so this is exact as long as no later score beats m by 2^16 (f16 range of
+                //     P_hi); if one does, the row sum turns inf/NaN, which is checked once per head, and
+                //   attempt 1 (safe, rare): the head is redone with the running max raised, and the sums
                 //     rescaled, in every pass.
-                auto zero_sums = [&]() {
+#pragma unroll 1
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool safe = (attempt != 0) || S2S_ALWAYS_RESCALE;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
-                        lH[q] = f32x4{0, 0, 0, 0}; lL[q] = f32x4{0, 0, 0, 0};
-                    }
-                };
-                auto load_va = [&](int tile0, h8 (&va)[HB]) {
+                for (int q = 0; q < NQ; ++q) {
+                    oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
+                    lH[q] = f32x4{0, 0, 0, 0}; lL[q] = f32x4{0, 0, 0, 0};
+                    negm[q] = f32x4{0, 0, 0, 0};
+                    m[q] = 0.0f;
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
+                    h8 ka[HK], va[HB];
+#pragma unroll
+                    for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
 #pragma unroll
                     for (int kb = 0; kb < HB; ++kb) {
-                        const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (tile0 + 2 * kb));
+                        const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
                         h4 v1 = h4{0, 0, 0, 0};                        // a K = 32 block past the last key tile: zero keys
-                        if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (tile0 + 2 * kb + 1));
+                        if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
                         va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     }
-                };
-                auto mask_phantom = [&](f32x4 (&sv)[NQ][HK]) {        // phantom keys -> -inf (only the last key tile has any)
+                    __builtin_amdgcn_sched_barrier(0);
+                    // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
+                    // beside the other's exponentials inside the same wave
+                    f32x4 s[NQ][HK];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (16 * (NKT - 1) + 4 * g + r >= TV) sv[q][HK - 1][r] = -__builtin_inff();
-                };
-                auto exp_pv = [&](f32x4 (&sv)[NQ][HK], const h8 (&va)[HB]) {
+                        for (int kt = 0; kt < HK; ++kt)
+                            s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+                    if (TV < 16 * NKT && h2 == NH - 1) {       // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        HL P[HB];
+                        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                        for (int kb = 0; kb < HB; ++kb) {
-                            unsigned h0, h1, h2_ = 0, h3 = 0, l0, l1, l2 = 0, l3 = 0;
-                            exp_split4(sv[q][2 * kb], one, h0, h1, l0, l1);
-                            if (2 * kb + 1 < HK) exp_split4(sv[q][2 * kb + 1], one, h2_, h3, l2, l3);
-                            P[kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
-                            P[kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
-                        }
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * (NKT - 1) + 4 * g + r >= TV) s[q][HK - 1][r] = -__builtin_inff();
+                    }
+                    if (h2 == 0 || safe) {
 #pragma unroll
-                        for (int kb = 0; kb < HB; ++kb) {
-                            if (S2S_ABL & 512) { asm volatile("" ::"v"(P[kb].hi), "v"(P[kb].lo)); continue; }
-                            oH[q] = MFMAH(va[kb], P[kb].hi, oH[q]);     // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                            oL[q] = MFMAH(va[kb], P[kb].lo, oL[q]);     // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
-                            if (!(S2S_ABL & 64)) {
-                                lH[q] = MFMAH(ones, P[kb].hi, lH[q]);   // every row: sum of the P actually used
-                                lL[q] = MFMAH(ones, P[kb].lo, lL[q]);
+                        for (int q = 0; q < NQ; ++q) {
+                            float mh = s[q][0][0];
+                            if (!(S2S_ABL & 32)) {
+#pragma unroll
+                                for (int kt = 0; kt < HK; ++kt)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[q][kt][r]);
+                                mh = max_g(mh);
+                            }
+                            if (h2 == 0) {
+                                m[q] = mh;
+                                negm[q] = f32x4{-mh, -mh, -mh, -mh};
+#pragma unroll
+                                for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
+                            } else {                              // safe attempt: raise the running max, rescale the sums
+                                const float delta = fmaxf(mh, 0.0f);
+                                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                                oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
+                                m[q] += delta;
+                                negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
+#pragma unroll
+                                for (int kt = 0; kt < HK; ++kt) s[q][kt] -= delta;
                             }
                         }
                     }
-                };
-                bool redo = S2S_ALWAYS_RESCALE;
-                if (!S2S_ALWAYS_RESCALE) {
-                    zero_sums();
-                    f32x4 sc[2][NQ][HK], negm[NQ];
-                    {
-                        h8 ka[HK];
-#pragma unroll
-                        for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * kt * 8);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) sc[0][q][kt] = MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0}));
-                    }
-                    if (TV < 16 * NKT && NH == 1) mask_phantom(sc[0]);
+                    HL P[NQ][HB];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        float mh = sc[0][q][0][0];
 #pragma unroll
-                        for (int kt = 0; kt < HK; ++kt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) mh = fmaxf(mh, sc[0][q][kt][r]);
-                        mh = max_g(mh);
-                        negm[q] = f32x4{-mh, -mh, -mh, -mh};
-#pragma unroll
-                        for (int kt = 0; kt < HK; ++kt) sc[0][q][kt] -= mh;
-                    }
-#pragma unroll
-                    for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
-                        h8 va[HB];
-                        load_va(h2 * HK, va);
-                        if (h2 + 1 < NH) {
-                            h8 ka[HK];
-#pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * ((h2 + 1) * HK + kt) * 8);
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                                for (int kt = 0; kt < HK; ++kt) sc[(h2 + 1) & 1][q][kt] = MFMAH(ka[kt], qb[q], negm[q]);
+                        for (int kb = 0; kb < HB; ++kb) {
+                            unsigned h0, h1, h2_ = 0, h3 = 0, l0, l1, l2 = 0, l3 = 0;
+                            exp_split4(s[q][2 * kb], one, h0, h1, l0, l1);
+                            if (2 * kb + 1 < HK) exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
+                            P[q][kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
+                            P[q][kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
                         }
-                        if (TV < 16 * NKT && h2 == NH - 1 && NH > 1) mask_phantom(sc[h2 & 1]);
-                        exp_pv(sc[h2 & 1], va);
-                    }
-                    bool bad = false;                          // inf or NaN row sum: some P_hi left the f16 range
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + lL[q][0] <= 3.0e38f);
-                    redo = __any(bad);
-#ifdef S2S_NO_FALLBACK       // test-only build: proves that test_peaked_attention... needs the fallback
-                    redo = false;
-#endif
+                        for (int kb = 0; kb < HB; ++kb) {
+                            if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
+                            oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                            oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                            if (!(S2S_ABL & 64)) {
+                            lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
+                            lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
+                            }
+                        }
+                    }
                 }
-                if (redo) {
-                    zero_sums();
-                    float m[NQ];
-                    f32x4 negm[NQ];
+                if (safe) break;
+                bool bad = false;                              // inf or NaN row sum: some P_hi left the f16 range
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) { m[q] = 0.0f; negm[q] = f32x4{0, 0, 0, 0}; }
-#pragma unroll 1
-                    for (int h2 = 0; h2 < NH; ++h2) {
-                        h8 ka[HK], va[HB];
-#pragma unroll
-                        for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
-                        load_va(h2 * HK, va);
-                        f32x4 sv[NQ][HK];
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) sv[q][kt] = MFMAH(ka[kt], qb[q], negm[q]);
-                        if (TV < 16 * NKT && h2 == NH - 1) mask_phantom(sv);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            float mh = sv[q][0][0];
-#pragma unroll
-                            for (int kt = 0; kt < HK; ++kt)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) mh = fmaxf(mh, sv[q][kt][r]);
-                            mh = max_g(mh);
-                            const float delta = (h2 == 0) ? mh : fmaxf(mh, 0.0f);
-                            const float alpha = __builtin_amdgcn_exp2f((h2 == 0) ? 0.0f : -delta);
-                            oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
-                            m[q] += delta;
-                            negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
-#pragma unroll
-                            for (int kt = 0; kt < HK; ++kt) sv[q][kt] -= delta;
-                        }
-                        exp_pv(sv, va);
-                    }
+                for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + lL[q][0] <= 3.0e38f);
+#ifdef S2S_NO_FALLBACK       // test-only build: proves that tests/test_gpu_parity.py::test_peaked_attention... needs the fallback
+                break;
+#endif
+                if (!__any(bad)) break;
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {

@@ -43,7 +43,7 @@ class Engine:
     """Weights resident on one GPU + the predict / export entry points."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: dict, device: Optional[int] = None,
-                 mode: str = "f32"):
+                 mode: str = "f16x3"):
         self._h = None
         L = _lib.lib()                       # raises when the HIP extension is missing
         if not torch.cuda.is_available():
@@ -64,7 +64,7 @@ class Engine:
         self._h = h
 
     @classmethod
-    def from_checkpoint(cls, path: str, device: Optional[int] = None, mode: str = "f32") -> "Engine":
+    def from_checkpoint(cls, path: str, device: Optional[int] = None, mode: str = "f16x3") -> "Engine":
         sd, cfg = load_checkpoint(path)
         return cls(sd, cfg, device, mode)
 
