@@ -1,0 +1,39 @@
+/* Plain-C consumer of include/s2s_hip.h: proves the boundary is a C ABI (no C++ or torch types leak).
+ * Built and run by tests/test_host_cpu.py with gcc; needs no GPU (only argument-checking paths are called). */
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include "s2s_hip.h"
+
+typedef size_t (*blob_floats_fn)(const s2s_config*);
+typedef int (*create_fn)(const s2s_config*, const void*, size_t, int, s2s_handle**);
+typedef const char* (*last_error_fn)(const s2s_handle*);
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
+    const char* names[] = {"s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks",
+                           "s2s_export_reads", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read"};
+    for (unsigned i = 0; i < sizeof names / sizeof *names; ++i)
+        if (!dlsym(lib, names[i])) { fprintf(stderr, "missing symbol %s\n", names[i]); return 4; }
+    blob_floats_fn blob_floats = (blob_floats_fn)dlsym(lib, "s2s_blob_floats");
+    create_fn create = (create_fn)dlsym(lib, "s2s_create");
+    last_error_fn last_error = (last_error_fn)dlsym(lib, "s2s_last_error");
+
+    s2s_config cfg = {9, S2S_T_ENC, S2S_T_DEC, S2S_DMODEL, S2S_DFF, S2S_HEADS, 2, 2, 1, 165.0f, S2S_MODE_F16X3};
+    const size_t n = blob_floats(&cfg);
+    if (n != 236804) { fprintf(stderr, "blob floats %zu\n", n); return 5; }    /* the reference's parameter count */
+    cfg.seq_kmer = 6;
+    if (blob_floats(&cfg) != 236804 - 64 * 15) return 6;
+    cfg.n_heads = 4;
+    if (blob_floats(&cfg) != 0) return 7;
+    s2s_handle* h = (s2s_handle*)1;
+    if (create(&cfg, 0, 0, 0, &h) != S2S_ERR_ARG || h != 0) return 8;
+    if (!strstr(last_error(0), "n_heads")) return 9;
+    cfg.n_heads = 8;
+    float dummy[4] = {0};
+    if (create(&cfg, dummy, sizeof dummy, 0, &h) != S2S_ERR_BLOB) return 10;
+    printf("CABI_OK %zu\n", n);
+    return 0;
+}

@@ -282,3 +282,47 @@ def test_full_size_properties():
     pa = ex["pa"][: offs[-1]]
     assert (pa != 0).all() and torch.equal(pa, a_sig[a_sig != 0])        # compaction keeps order and values
     eng.close()
+
+
+EDGE_PARAMS = [
+    dict(),                                                           # defaults (injected variates below)
+    dict(duration_sampling=False, dwell_mean=0.0, noise_std=0.0),     # zero dwell: every row is pad + position_enc
+    dict(duration_sampling=False, dwell_mean=0.4, noise_std=0.0),     # rounds to 0 as well
+    dict(duration_sampling=False, dwell_mean=250.0, noise_std=0.0),   # first k-mer fills the whole chunk
+    dict(min_duration=300.0),                                         # clamp beyond the chunk length
+    dict(min_duration=0.0, noise_std=-1.0),                           # Gamma values below 1 clamp to 1; negative noise_std = off
+    dict(noise_sampling=True, min_noise=5.0, noise_std=0.5),          # sigma clamp dominates
+    dict(noise_sampling=False, noise_std=50.0),                       # large constant noise: many samples clamp to 0
+]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("over", EDGE_PARAMS, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "defaults")
+def test_edge_inputs_and_parameters(mode, over):
+    """Ragged and degenerate inputs the reference accepts (reads of length k, k+15, k+16; all-N; lower case = unknown
+    letters; literal '_'), under parameter extremes, against the oracle."""
+    sd, cfg = load_ckpt("k9")
+    eng = S.Engine(sd, cfg, mode=mode)
+    k = 9
+    reads = ["ACGTACGTA", "ACGTACGTAC" * 2 + "ACGT", "ACGTACGTAC" * 2 + "ACGTA", "N" * 60, "acgtacgtacgtacgtacgtacgtacgt",
+             "ACGT_ACGT__ACGTACGTACGTAC", "ACGTNNNNNNNNNACGTACGTRYKMACGTACGTACGATCGATCGATCGATTTTTTTTTTTTTTTTTTTGGGGGGGGGGGGG"]
+    bases, nv, first = S.encode_reads(reads, k)
+    codes = np.concatenate([O.encode_read(r, k) for r in reads], 0)
+    B = bases.shape[0]
+    assert B == codes.shape[0] and nv.tolist()[0] == 1
+    gen = torch.Generator().manual_seed(5)
+    g = torch.rand(B, 16, generator=gen) * 30                      # includes values < 1
+    z = torch.randn(B, 250, generator=gen)
+    p = P(**over)
+    ref = O.predict_chunks(sd, cfg, codes, O.PredictParams(**p), inject_g=g, inject_z01=z)
+    out = eng.predict_chunks(torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), S.PredictParams(**p),
+                             inject_g=g.cuda(), inject_z01=z.cuda())
+    assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
+    y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
+    assert np.isfinite(y).all()
+    # a sample the noise pushes to within rounding of 0 may clamp on one side only: allow that where |ref| is tiny
+    mism = (y == 0) != (r == 0)
+    assert (np.abs(r[mism]) < 1e-3).all() and (np.abs(y[mism]) < 1e-3).all() and mism.mean() < 1e-3
+    d = np.abs(y - r)
+    assert d.mean() < MAE_TOL and d.max() < 5e-3, (d.mean(), d.max())
+    eng.close()

@@ -98,3 +98,13 @@ def test_engine_fails_loudly_without_gpu():
     sd, cfg = load_ckpt("k9")
     with pytest.raises(RuntimeError):
         S.Engine(sd, cfg)
+
+
+def test_plain_c_consumer(tmp_path):
+    """gcc-compiled C program dlopens the library, resolves every symbol and exercises the argument checks."""
+    import subprocess
+    exe = tmp_path / "cabi_check"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "cabi_check.c"), "-o", str(exe), "-ldl"], check=True)
+    r = subprocess.run([str(exe), _lib._LIB_DEFAULT], capture_output=True, text=True)
+    assert r.returncode == 0 and "CABI_OK 236804" in r.stdout, (r.returncode, r.stdout, r.stderr)
