@@ -132,6 +132,14 @@ int s2s_predict_chunks(s2s_handle* h, void* stream, const uint8_t* bases, const 
                        const float* inject_g, const float* inject_zdw, const float* inject_z01,
                        float* out_signal, int32_t* out_dur, const s2s_debug* dbg);
 
+/* Same as s2s_predict_chunks without materialising the chunk windows: `read_bytes` (device) holds whole reads back
+ * to back, each padded with '_' to 16*C + k - 1 bytes (C = its chunk count); chunk b is the 16+k-1 bytes at
+ * read_bytes + chunk_start[b] (device int64 [B]).  This is what process_read/split_sequence (dataloader.py:358-398,
+ * utils.py:350-356) produce, minus the one-hot: adjacent chunks of a read overlap by k-1 bytes in place. */
+int s2s_predict_packed(s2s_handle* h, void* stream, const uint8_t* read_bytes, const int64_t* chunk_start,
+                       const uint8_t* n_valid, int64_t first_global_chunk, int32_t B, const s2s_params* params,
+                       float* out_signal, int32_t* out_dur);
+
 /* Replaces the per-read cat + zero-strip of export_and_clear_results (model.py:284-286) and the
  * pA -> int16 conversion of BLOW5Writer/POD5Writer.save (signal_io.py:134-141, 246-253).
  *

@@ -24,7 +24,7 @@ class S2SDebug(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("emb_out", "enc_out", "sigma", "conc", "rate", "g", "y_scaled", "z01")]
 
 
-EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks",
+EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
            "s2s_export_reads", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read")
 
 
@@ -50,6 +50,8 @@ def lib():
     L.s2s_predict_chunks.restype = i32
     L.s2s_predict_chunks.argtypes = [vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp, vp, vp, vp,
                                      C.POINTER(S2SDebug)]
+    L.s2s_predict_packed.restype = i32
+    L.s2s_predict_packed.argtypes = [vp, vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp]
     L.s2s_export_reads.restype = i32
     L.s2s_export_reads.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i64, f32, f32, f32, i32]
     L.s2s_philox_u32.restype = i32

@@ -80,10 +80,9 @@ def pack_reads(seqs: Sequence[str], k: int):
     C = -(-n_kmer // T_ENC)
     padded = np.where(C > 0, T_ENC * C + k - 1, 0)
     base = np.concatenate([[0], np.cumsum(padded)])
-    flat = np.full(int(base[-1]) + 1, ord("_"), dtype=np.uint8)
-    for i, s_ in enumerate(seqs):
-        if C[i] > 0:
-            flat[base[i]: base[i] + lens[i]] = np.frombuffer(s_.encode("latin-1"), dtype=np.uint8)
+    # one join instead of a per-read array copy; reads that yield no chunk (len < k) contribute nothing
+    blob = b"".join((s_.encode("latin-1") + b"_" * int(padded[i] - lens[i])) if C[i] > 0 else b"" for i, s_ in enumerate(seqs))
+    flat = np.frombuffer(blob + b"_", dtype=np.uint8)
     read_first = np.concatenate([[0], np.cumsum(C)]).astype(np.int32)
     within = np.arange(int(read_first[-1])) - np.repeat(read_first[:-1], C)          # chunk index inside its read
     chunk_start = np.repeat(base[:-1], C) + T_ENC * within

@@ -58,7 +58,7 @@ __device__ __forceinline__ int base_code(unsigned char ch) {       // utils.py:7
 template <int MODE>   // 0: f32-input MFMA, 1: split-f16 (s2s_device_h.h)
 __global__ __launch_bounds__(64) void s2s_frontend_kernel(
     const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
-    const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
+    const long long* __restrict__ chunk_start, const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
     const float* __restrict__ inj_g, const float* __restrict__ inj_zdw, float* __restrict__ ws_enc,
     float* __restrict__ ws_sigma, int* __restrict__ out_dur, DebugDev dbg, long long dbg_base) {
     constexpr int LDS_BYTES = (MODE == 1) ? AttnLdsH<1, 1, 1>::BYTES : AttnLds<1>::BYTES;
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
     asm volatile("" : "+s"(one));
     const int b = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int k = M.k, nb = S2S_T_ENC + k - 1;
-    const uint8_t* bp = bases + (size_t)b * nb;
+    // chunk b's 16+k-1 bytes: a row of the dense [B][16+k-1] array, or a window of the packed read buffer
+    const uint8_t* bp = chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb;
     const int nv = n_valid[b];
 
     // ---- src_emb on the one-hot k-mer == bias + sum of k gathered columns of W_emb (modules.py:70-73)
@@ -794,7 +795,7 @@ void s2s_destroy(s2s_handle* h) {
 
 const char* s2s_last_error(const s2s_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const uint8_t* n_valid, int64_t first_global_chunk,
+static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, const int64_t* chunk_start, const uint8_t* n_valid, int64_t first_global_chunk,
                        int32_t B, const s2s_params* params, const float* inject_g, const float* inject_zdw,
                        const float* inject_z01, float* out_signal, int32_t* out_dur, const s2s_debug* dbg) {
     if (!h) return S2S_ERR_ARG;
@@ -817,12 +818,12 @@ int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const
     for (int64_t s = 0; s < B; s += h->tile) {
         const int n = (int)((B - s < h->tile) ? (B - s) : h->tile);
         if (h->cfg.compute_mode != S2S_MODE_F32)
-            hipLaunchKernelGGL(s2s_frontend_kernel<1>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, bases + (size_t)s * nb,
-                               n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
+            hipLaunchKernelGGL(s2s_frontend_kernel<1>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, chunk_start ? bases : bases + (size_t)s * nb,
+                               reinterpret_cast<const long long*>(chunk_start ? chunk_start + s : nullptr), n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
                                inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
         else
-            hipLaunchKernelGGL(s2s_frontend_kernel<0>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, bases + (size_t)s * nb,
-                               n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
+            hipLaunchKernelGGL(s2s_frontend_kernel<0>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, chunk_start ? bases : bases + (size_t)s * nb,
+                               reinterpret_cast<const long long*>(chunk_start ? chunk_start + s : nullptr), n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
                                inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
         EventPair ev{};
         if (h->profiling) {
@@ -853,6 +854,21 @@ int s2s_predict_chunks(s2s_handle* h, void* stream_, const uint8_t* bases, const
     }
     HIP_TRY(h, hipGetLastError());
     return S2S_OK;
+}
+
+int s2s_predict_chunks(s2s_handle* h, void* stream, const uint8_t* bases, const uint8_t* n_valid, int64_t first_global_chunk,
+                       int32_t B, const s2s_params* params, const float* inject_g, const float* inject_zdw,
+                       const float* inject_z01, float* out_signal, int32_t* out_dur, const s2s_debug* dbg) {
+    return predict_impl(h, stream, bases, nullptr, n_valid, first_global_chunk, B, params, inject_g, inject_zdw, inject_z01,
+                        out_signal, out_dur, dbg);
+}
+
+int s2s_predict_packed(s2s_handle* h, void* stream, const uint8_t* read_bytes, const int64_t* chunk_start,
+                       const uint8_t* n_valid, int64_t first_global_chunk, int32_t B, const s2s_params* params,
+                       float* out_signal, int32_t* out_dur) {
+    if (h && !chunk_start) return fail(h, S2S_ERR_ARG, "chunk_start is NULL");
+    return predict_impl(h, stream, read_bytes, chunk_start, n_valid, first_global_chunk, B, params, nullptr, nullptr, nullptr,
+                        out_signal, out_dur, nullptr);
 }
 
 int s2s_export_reads(s2s_handle* h, void* stream_, const float* signal, int32_t B, const int32_t* read_first, int32_t R,

@@ -126,6 +126,26 @@ class Engine:
         self._check(rc, "s2s_predict_chunks")
         return out
 
+    def predict_packed(self, read_bytes: torch.Tensor, chunk_start: torch.Tensor, n_valid: torch.Tensor,
+                       params: PredictParams, first_global_chunk: int = 0):
+        """Chunks addressed inside a packed read buffer (chunker.pack_reads): read_bytes uint8 [N], chunk_start int64
+        [B], n_valid uint8 [B], all on the engine's device -> dict(signal [B,250], dur [B,16])."""
+        B = int(chunk_start.shape[0])
+        for name, t, dt in (("read_bytes", read_bytes, torch.uint8), ("chunk_start", chunk_start, torch.int64),
+                            ("n_valid", n_valid, torch.uint8)):
+            if t.dtype != dt or not t.is_contiguous() or t.device != self.device or t.dim() != 1:
+                raise ValueError(f"{name} must be a contiguous 1-D {dt} tensor on {self.device}")
+        if n_valid.shape[0] != B:
+            raise ValueError("n_valid and chunk_start differ in length")
+        sig = torch.empty(B, T_DEC, dtype=torch.float32, device=self.device)
+        dur = torch.empty(B, T_ENC, dtype=torch.int32, device=self.device)
+        p = params.to_c()
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().s2s_predict_packed(self._h, self._stream(), _ptr(read_bytes), _ptr(chunk_start), _ptr(n_valid),
+                                               int(first_global_chunk), B, C.byref(p), _ptr(sig), _ptr(dur))
+        self._check(rc, "s2s_predict_packed")
+        return {"signal": sig, "dur": dur}
+
     # ------------------------------------------------------------------ export
     def export_reads(self, signal: torch.Tensor, read_first: torch.Tensor, digitisation: float = 0.0,
                      signal_range: float = 1.0, offset_mean: float = 0.0, rna: bool = False, want_pa: bool = True,

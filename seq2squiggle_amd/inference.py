@@ -80,49 +80,75 @@ def iter_batches(reads: Iterable[Tuple[str, str]], k: int, batch_size: int, devi
 def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
                   max_chunks: int = 32768) -> int:
     """The predict loop without per-chunk Python objects: whole reads are grouped into super-batches of about
-    `max_chunks` chunks; per super-batch one H2D of the read bytes, a gather into chunk windows, s2s_predict_chunks,
-    s2s_export_reads (zero-strip + int16 conversion on the GPU), one D2H of the packed int16 samples, then the
-    writer.  Produces the same records as predict_step + export_and_clear_results + writer.save()."""
+    `max_chunks` chunks; per super-batch one H2D of the packed read bytes, s2s_predict_packed, s2s_export_reads
+    (zero-strip + int16 conversion on the GPU), one D2H of the packed int16 samples, then the writer.  Produces the
+    same records as predict_step + export_and_clear_results + writer.save().
+
+    Three stages overlap: while the GPU works on super-batch i the host samples/packs i+1, and a writer thread
+    compresses and writes i-1.  Record metadata (the np.random offset draws of signal_io.py:129-132) is built on the
+    calling thread in read order, so the output does not depend on thread timing."""
+    from concurrent.futures import ThreadPoolExecutor
     k = model.config["seq_kmer"]
-    nb = 16 + k - 1
     dev = model.device
     rna = profile_name.startswith("rna")
-    win = torch.arange(nb, device=dev)
     total = 0
+    io = ThreadPoolExecutor(max_workers=1)
+    pending = None            # the writer job of the previous super-batch
+    inflight = None           # (ids, export result) launched on the GPU, not yet fetched
 
-    def flush(group):
+    def launch(group):
         nonlocal total
-        ids = [n for _, n in group]
         flat, chunk_start, n_valid, read_first = pack_reads([s for s, _ in group], k)
         B = int(read_first[-1])
         if B == 0:
-            return
-        flat_d = torch.from_numpy(flat).to(dev, non_blocking=True)
-        bases = flat_d[torch.from_numpy(chunk_start).to(dev).unsqueeze(1) + win]           # [B, nb] gather
-        out = model.engine.predict_chunks(bases.contiguous(), torch.from_numpy(n_valid).to(dev), model._params(),
+            return None
+        out = model.engine.predict_packed(torch.from_numpy(flat).to(dev, non_blocking=True),
+                                          torch.from_numpy(chunk_start).to(dev, non_blocking=True),
+                                          torch.from_numpy(n_valid).to(dev, non_blocking=True), model._params(),
                                           first_global_chunk=model.chunks_done)
         model.chunks_done += B
+        total += B
         ex = model.engine.export_reads(out["signal"], torch.from_numpy(read_first).to(dev), profile_dict["digitisation"],
                                        profile_dict["range"], profile_dict["offset_mean"], rna=rna, want_pa=False,
                                        want_dac=True)
+        return [n for _, n in group], ex
+
+    def collect(job):
+        nonlocal pending
+        ids, ex = job
         offs = ex["offsets"].cpu().numpy()
         dac = ex["dac"][: int(offs[-1])].cpu().numpy()
-        writer.save_dac(ids, dac, offs)
-        total += B
+        recs = writer.dac_records(ids, dac, offs)
+        if pending is not None:
+            pending.result()
+        pending = io.submit(writer.write_records, recs)
 
-    group, n = [], 0
-    for seq, name in reads:
-        c = _n_chunks(len(seq), k)
-        if c == 0:
-            logger.debug(f"Skipped read {name}.")
-            continue
-        group.append((seq, name))
-        n += c
-        if n >= max_chunks:
-            flush(group)
-            group, n = [], 0
-    if group:
-        flush(group)
+    try:
+        group, n = [], 0
+        for seq, name in reads:
+            c = _n_chunks(len(seq), k)
+            if c == 0:
+                logger.debug(f"Skipped read {name}.")
+                continue
+            group.append((seq, name))
+            n += c
+            if n >= max_chunks:
+                job = launch(group)
+                if inflight is not None:
+                    collect(inflight)
+                inflight = job
+                group, n = [], 0
+        if group:
+            job = launch(group)
+            if inflight is not None:
+                collect(inflight)
+            inflight = job
+        if inflight is not None:
+            collect(inflight)
+        if pending is not None:
+            pending.result()
+    finally:
+        io.shutdown(wait=True)
     return total
 
 

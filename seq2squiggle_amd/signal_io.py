@@ -89,6 +89,7 @@ class BLOW5Writer:
         self.start_time = 0
         self.n_written = 0
         self.binary = self.filename.endswith(".blow5")
+        self.compress_level = 1               # zlib level of BLOW5 records; any level is a valid zlib stream
 
     # ------------------------------------------------------------------ header
     def header_attributes(self) -> dict:
@@ -146,8 +147,15 @@ class BLOW5Writer:
     def save_dac(self, read_ids, dac: np.ndarray, offsets: np.ndarray):
         """Streaming path: samples already converted to int16 on the GPU (s2s_export_reads), packed read after read;
         read r is dac[offsets[r]:offsets[r+1]].  Same records and append semantics as save()."""
-        recs = (self._record(rid, dac[offsets[i]:offsets[i + 1]]) for i, rid in enumerate(read_ids)
-                if offsets[i + 1] > offsets[i])
+        self._write(self.dac_records(read_ids, dac, offsets))
+
+    def dac_records(self, read_ids, dac: np.ndarray, offsets: np.ndarray) -> list:
+        """The records save_dac() writes, built now (read numbering and the offset draws happen here, in order)."""
+        return [self._record(rid, dac[offsets[i]:offsets[i + 1]]) for i, rid in enumerate(read_ids)
+                if offsets[i + 1] > offsets[i]]
+
+    def write_records(self, recs) -> None:
+        """Append already-built records; safe to call from one background thread at a time."""
         self._write(recs)
 
     def save(self):
@@ -177,15 +185,14 @@ class BLOW5Writer:
     # BLOW5 v0.2.0: 64-byte file header, u32 size + ASCII header, records (u64 size + zlib stream), "5WOLB"
     _EOF = b"5WOLB"
 
-    @staticmethod
-    def _blow5_record(r) -> bytes:
+    def _blow5_record(self, r) -> bytes:
         rid, ch = r["read_id"].encode(), r["channel_number"].encode()
         body = (struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", r["read_group"], r["digitisation"], r["offset"],
                                                                  r["range"], r["sampling_rate"], r["len_raw_signal"])
                 + np.ascontiguousarray(r["signal"]).astype("<i2").tobytes()
                 + struct.pack("<H", len(ch)) + ch
                 + struct.pack("<diBQ", r["median_before"], r["read_number"], r["start_mux"], r["start_time"]))
-        z = zlib.compress(body)
+        z = zlib.compress(body, self.compress_level)
         return struct.pack("<Q", len(z)) + z
 
     def _save_blow5(self, append: bool, recs):

@@ -172,6 +172,24 @@ def test_batch_and_offset_invariance(case):
     assert not torch.equal(full["dur"], other["dur"])
 
 
+def test_packed_reads_equal_chunk_windows(case):
+    """s2s_predict_packed (chunks addressed inside the packed read buffer) == s2s_predict_chunks on the windows."""
+    from seq2squiggle_amd import chunker
+    eng, dev, k = case["eng"], case["dev"], case["cfg"]["seq_kmer"]
+    rng = np.random.default_rng(5)
+    reads = ["".join(rng.choice(list("ACGTN"), int(n))) for n in rng.integers(k, 700, size=40)] + ["A" * k, "ACGT" * 4000]
+    flat, cs, nv, rf = chunker.pack_reads(reads, k)
+    bases, nv2, rf2 = chunker.encode_reads(reads, k)
+    assert np.array_equal(nv, nv2) and np.array_equal(rf, rf2)
+    pp = S.PredictParams(**P(seed=99))
+    a = eng.predict_chunks(torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev), pp, first_global_chunk=7)
+    b = eng.predict_packed(torch.from_numpy(flat).to(dev), torch.from_numpy(cs).to(dev), torch.from_numpy(nv).to(dev), pp,
+                           first_global_chunk=7)
+    assert torch.equal(a["signal"], b["signal"]) and torch.equal(a["dur"], b["dur"])
+    with pytest.raises(ValueError):
+        eng.predict_packed(torch.from_numpy(flat).to(dev), torch.from_numpy(cs[:-1]).to(dev), torch.from_numpy(nv).to(dev), pp)
+
+
 def test_empty_batch_and_bad_args(case):
     eng, dev = case["eng"], case["dev"]
     nb = 16 + case["cfg"]["seq_kmer"] - 1
