@@ -23,6 +23,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ALWAYS_RESCALE
 #define S2S_ALWAYS_RESCALE 0
 #endif
+#define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
 #define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 struct HL { h8 hi, lo; };
@@ -135,7 +136,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + wave * G::Q_WAVE_BYTES);
     const float* ws = W + L.stream_h + lane * 4;
     f32x4 fa[4], fb[4];
-    load_unit(fa, ws); ws += 1024;                    // Wk, pair 0
+    load_unit(fa, ws); WS_ADVP(1024, 2048);                    // Wk, pair 0
 
     HL xb[NQ][2];                                     // block input as B operands
 #pragma unroll
@@ -146,7 +147,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
-        load_unit(fb, ws); ws += 1024;                // Wv, pair p
+        load_unit(fb, ws); WS_ADVP(1024, 2048);                // Wv, pair p
         const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g), bv = ldg4(W + L.bv + 16 * p + 4 * g);
         __builtin_amdgcn_sched_barrier(0);
         // bias is added after the GEMM: the inline-asm split below must read results of compiler-visible
@@ -156,7 +157,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
         mm_unit_h<NQ>(ak, fa, xb);
         __builtin_amdgcn_sched_barrier(0);
-        load_unit(fa, ws); ws += 1024;                // Wk, pair p+1 (after the last pair: Wq, pair 0)
+        load_unit(fa, ws); WS_ADVP(1024, 2048);                // Wk, pair p+1 (after the last pair: Wq, pair 0)
         __builtin_amdgcn_sched_barrier(0);
         mm_unit_h<NQ>(av, fb, xb);
         const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // accumulator rows 4g..4g+3 = head, d0..d0+3
@@ -198,7 +199,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int pp = 0; pp < 2; ++pp) {
             const int p = 2 * u + pp;
             // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
-            if (pp == 0) { load_unit(fb, ws); ws += 1024; } else { load_unit(fa, ws); ws += 1024; }
+            if (pp == 0) { load_unit(fb, ws); WS_ADVP(1024, 8192); } else { load_unit(fa, ws); WS_ADVP(1024, 8192); }
             const f32x4 bq = ldg4(W + L.bq_nat + 16 * p + 4 * g);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 qa[NQ];
@@ -354,7 +355,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         HL ob[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q], one);
-            load_unit(fb, ws); ws += 1024;                // Wfc(u), m-tiles 2-3
+            load_unit(fb, ws); WS_ADVP(1024, 8192);                // Wfc(u), m-tiles 2-3
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {        // unit = [mt a hi][mt a lo][mt b hi][mt b lo]
@@ -372,7 +373,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             }
             if (half == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                load_unit(fa, ws); ws += 1024;        // next iteration's Wq (after the last: W1 unit 0)
+                load_unit(fa, ws); WS_ADVP(1024, 8192);        // next iteration's Wq (after the last: W1 unit 0)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -385,7 +386,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     f32x4 ring[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
-    load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); ws += 2048;
+    load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); WS_ADVP(2048, 16384);
     __builtin_amdgcn_sched_barrier(0);
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
     DIAG_STAMP(4);
@@ -409,7 +410,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
-            load_unit(ring[(mt + 3) & 3], ws); ws += 1024;
+            load_unit(ring[(mt + 3) & 3], ws); WS_ADVP(1024, 16384);
             __builtin_amdgcn_sched_barrier(0);
             mm_unit_h<NQ>(t, ring[mt & 3], x1b);
             __builtin_amdgcn_sched_barrier(0);
@@ -426,7 +427,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
-            load_unit(ring[(mt + 3) & 3], ws); ws += 1024;
+            load_unit(ring[(mt + 3) & 3], ws); WS_ADVP(1024, 16384);
             __builtin_amdgcn_sched_barrier(0);
             mm_unit_h<NQ>(t, ring[mt & 3], hb);
             __builtin_amdgcn_sched_barrier(0);

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
 """Timing-only ablations of the decoder kernel (-DS2S_ABL=mask builds; outputs are garbage).
 f32 block: bit0 no softmax VALU, bit1 no LDS operand reads, bit2 no barriers, bit3 no K/V LDS stores, bit4 no LayerNorm.
-f16 block: 1 no exp, 2 no split, 4 no barriers, 32 no max/branch, 64 no row-sum MFMAs, 128 no FFN, 256 one key pass of four."""
+f16 block: 1 no exp, 2 no split, 4 no barriers, 32 no max/branch, 64 no row-sum MFMAs, 128 no FFN, 256 one key pass of four; unit loads L1-hot: 2048 K/V phase, 8192 attention phase, 16384 FFN.
+S2S_ABL_FLAGS adds extra -D flags (e.g. -DS2S_NO_FALLBACK so that garbage data cannot take the safe softmax path)."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 masks = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 31]
 for m in masks:
     lib = os.path.join(ROOT, "seq2squiggle_amd", "lib", f"libs2s_hip_abl{m}.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", f"-DS2S_ABL={m}",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", f"-DS2S_ABL={m}", *os.environ.get("S2S_ABL_FLAGS", "").split(),
                     "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
     env = dict(os.environ, S2S_HIP_LIB=lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "420",
