@@ -140,7 +140,7 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST"):      # (the env var exercises the RCCL calls on one GPU)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
