@@ -128,6 +128,108 @@ __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const f
     }
 }
 
+// Softmax(Q K^T) V of one head for this wave's NQ query tiles: sums of V.P (oH: P_hi, oL: P_lo; rows 0-7 against V_hi,
+// rows 8-15 against V_lo) and of P (lH, lL), over NH passes of HK key tiles.  Pass 0 subtracts its own column max; later
+// passes get "score - m" straight out of the MFMA (the accumulator starts at -m).
+//   SAFE = false (fast): m stays the pass-0 max (+ S2S_SHIFT_BIAS) and later passes compute no max at all.  Softmax is
+//     shift-invariant, so this is exact as long as no later score beats m by the f16 range of P_hi; if one does, the
+//     row sum turns inf/NaN, which the caller checks once per head, and then runs
+//   SAFE = true (rare): a textbook online softmax, the running max raised and the sums rescaled in every pass.
+template <int NQ, int NKT, int TV, bool SAFE>
+__device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, const _Float16* __restrict__ vp, const h8 (&qb)[NQ],
+                                           const h8 ones, const float one, const int g, f32x4 (&oH)[NQ], f32x4 (&oL)[NQ],
+                                           f32x4 (&lH)[NQ], f32x4 (&lL)[NQ]) {
+    constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;
+    f32x4 negm[NQ];
+    float m[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
+        lH[q] = f32x4{0, 0, 0, 0}; lL[q] = f32x4{0, 0, 0, 0};
+        negm[q] = f32x4{0, 0, 0, 0};
+        m[q] = 0.0f;
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
+        h8 ka[HK], va[HB];
+#pragma unroll
+        for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) {
+            const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
+            h4 v1 = h4{0, 0, 0, 0};                        // a K = 32 block past the last key tile: zero keys
+            if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
+            va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
+        // beside the other's exponentials inside the same wave
+        f32x4 s[NQ][HK];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int kt = 0; kt < HK; ++kt)
+                s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+        if (TV < 16 * NKT && h2 == NH - 1) {       // phantom keys -> -inf (only the last key tile has any)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * (NKT - 1) + 4 * g + r >= TV) s[q][HK - 1][r] = -__builtin_inff();
+        }
+        if (h2 == 0 || SAFE) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float mh = s[q][0][0];
+                if (!(S2S_ABL & 32)) {
+#pragma unroll
+                    for (int kt = 0; kt < HK; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[q][kt][r]);
+                    mh = max_g(mh);
+                }
+                if (h2 == 0) {
+                    if (!SAFE) mh += S2S_SHIFT_BIAS;
+                    m[q] = mh;
+                    negm[q] = f32x4{-mh, -mh, -mh, -mh};
+#pragma unroll
+                    for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
+                } else {                              // safe attempt: raise the running max, rescale the sums
+                    const float delta = fmaxf(mh, 0.0f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
+                    m[q] += delta;
+                    negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
+#pragma unroll
+                    for (int kt = 0; kt < HK; ++kt) s[q][kt] -= delta;
+                }
+            }
+        }
+        HL P[NQ][HB];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) {
+                unsigned h0, h1, h2_ = 0, h3 = 0, l0, l1, l2 = 0, l3 = 0;
+                exp_split4(s[q][2 * kb], one, h0, h1, l0, l1);
+                if (2 * kb + 1 < HK) exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
+                P[q][kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
+                P[q][kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
+            }
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) {
+                if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
+                oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                if (!(S2S_ABL & 64)) {
+                lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
+                lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
+                }
+            }
+        }
+    }
+}
+
 // One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
 template <int NQ, int WAVES, int NKT, int TV>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
@@ -234,113 +336,20 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     qb[q] = *reinterpret_cast<const h8*>(Ql + (((q * 2 + (g & 1)) * 2 + hh) * 16 + c) * 8);
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
-                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ], negm[NQ];
-                float m[NQ];
-                // Online softmax over NH passes of HK key tiles.  Pass 0 subtracts its own column max; later
-                // passes get "score - m" straight out of the MFMA (the accumulator starts at -m).
-                //   attempt 0 (fast): m stays the pass-0 max and later passes compute no max at all.  Softmax is
-                //     shift-invariant, so this is exact as long as no later score beats m by 2^16 (f16 range of
-                //     P_hi); if one does, the row sum turns inf/NaN, which is checked once per head, and
-                //   attempt 1 (safe, rare): the head is redone with the running max raised, and the sums
-                //     rescaled, in every pass.
-#pragma unroll 1
-                for (int attempt = 0; attempt < 2; ++attempt) {
-                const bool safe = (attempt != 0) || S2S_ALWAYS_RESCALE;
+                f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
+                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+#if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)   // (NO_FALLBACK: test-only build, proves test_peaked_attention... needs the redo)
+                {
+                    bool bad = false;                          // inf or NaN row sum: some P_hi left the f16 range
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    oH[q] = f32x4{0, 0, 0, 0}; oL[q] = f32x4{0, 0, 0, 0};
-                    lH[q] = f32x4{0, 0, 0, 0}; lL[q] = f32x4{0, 0, 0, 0};
-                    negm[q] = f32x4{0, 0, 0, 0};
-                    m[q] = 0.0f;
-                }
-#pragma unroll
-                for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
-                    h8 ka[HK], va[HB];
-#pragma unroll
-                    for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
-#pragma unroll
-                    for (int kb = 0; kb < HB; ++kb) {
-                        const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
-                        h4 v1 = h4{0, 0, 0, 0};                        // a K = 32 block past the last key tile: zero keys
-                        if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
-                        va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
-                    // beside the other's exponentials inside the same wave
-                    f32x4 s[NQ][HK];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                        for (int kt = 0; kt < HK; ++kt)
-                            s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
-                    if (TV < 16 * NKT && h2 == NH - 1) {       // phantom keys -> -inf (only the last key tile has any)
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (16 * (NKT - 1) + 4 * g + r >= TV) s[q][HK - 1][r] = -__builtin_inff();
-                    }
-                    if (h2 == 0 || safe) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            float mh = s[q][0][0];
-                            if (!(S2S_ABL & 32)) {
-#pragma unroll
-                                for (int kt = 0; kt < HK; ++kt)
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) mh = fmaxf(mh, s[q][kt][r]);
-                                mh = max_g(mh);
-                            }
-                            if (h2 == 0) {
-                                if (!safe) mh += S2S_SHIFT_BIAS;
-                                m[q] = mh;
-                                negm[q] = f32x4{-mh, -mh, -mh, -mh};
-#pragma unroll
-                                for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
-                            } else {                              // safe attempt: raise the running max, rescale the sums
-                                const float delta = fmaxf(mh, 0.0f);
-                                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                                oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
-                                m[q] += delta;
-                                negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
-#pragma unroll
-                                for (int kt = 0; kt < HK; ++kt) s[q][kt] -= delta;
-                            }
-                        }
-                    }
-                    HL P[NQ][HB];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-                        for (int kb = 0; kb < HB; ++kb) {
-                            unsigned h0, h1, h2_ = 0, h3 = 0, l0, l1, l2 = 0, l3 = 0;
-                            exp_split4(s[q][2 * kb], one, h0, h1, l0, l1);
-                            if (2 * kb + 1 < HK) exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
-                            P[q][kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
-                            P[q][kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
-                        }
-#pragma unroll
-                        for (int kb = 0; kb < HB; ++kb) {
-                            if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
-                            oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                            oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
-                            if (!(S2S_ABL & 64)) {
-                            lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
-                            lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
-                            }
-                        }
-                    }
-                }
-                if (safe) break;
-                bool bad = false;                              // inf or NaN row sum: some P_hi left the f16 range
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + lL[q][0] <= 3.0e38f);
-#ifdef S2S_NO_FALLBACK       // test-only build: proves that tests/test_gpu_parity.py::test_peaked_attention... needs the fallback
-                break;
+                    for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + lL[q][0] <= 3.0e38f);
+                    const bool redo = __any(bad);
+#ifdef S2S_DIAG
+                    if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
 #endif
-                if (!__any(bad)) break;
+                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
                 }
+#endif
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const f32x4 t = oH[q] + oL[q];

@@ -28,3 +28,5 @@ nw = bases.shape[0] * 8
 for i in sorted(names):
     print(f"{names[i]:40s} {v[i] / nw:12.0f} cycles/wave  {100 * v[i] / tot:5.1f} %")
 print(f"total {tot / nw:.0f} cycles per wave per chunk")
+if v[11]:
+    print(f"safe-path redos: {v[10]} of {v[11]} (wave, head) softmax runs = {100 * v[10] / v[11]:.2f} %")
