@@ -192,8 +192,14 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
                     if (!SAFE) mh += S2S_SHIFT_BIAS;
                     m[q] = mh;
                     negm[q] = f32x4{-mh, -mh, -mh, -mh};
+                    // "score - m" comes from the matrix cores again: 8 issue cycles per tile instead of four subtractions (16)
+                    if (!SAFE && !(TV < 16 * NKT && NH == 1)) {
 #pragma unroll
-                    for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
+                        for (int kt = 0; kt < HK; ++kt) s[q][kt] = MFMAH(ka[kt], qb[q], negm[q]);
+                    } else {                                      // (a single-pass block has already masked its phantom keys in s)
+#pragma unroll
+                        for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
+                    }
                 } else {                              // safe attempt: raise the running max, rescale the sums
                     const float delta = fmaxf(mh, 0.0f);
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
