@@ -114,6 +114,23 @@ __device__ __forceinline__ void mm_unit_h(f32x4 (&acc)[NQ], const f32x4 (&f)[4],
     }
 }
 
+// acc[q] += (W_unit * x[q])^T: the A and B fragments of the K = 32 MFMA have the same lane layout, so swapping the operands
+// transposes the product for free -- rows of the accumulator tile are then 4 consecutive TIME columns, its column one
+// output feature (used for V^T, whose LDS rows run along the keys).
+template <int NQ>
+__device__ __forceinline__ void mm_unit_h_t(f32x4 (&acc)[NQ], const f32x4 (&f)[4], const HL (&x)[NQ][2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const h8 wh = as_h8(f[2 * kb]), wl = as_h8(f[2 * kb + 1]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].hi, wh, acc[q]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].lo, wh, acc[q]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].hi, wl, acc[q]);
+    }
+}
+
 // y = W x + b for a 64x64 Linear stored as 4 f16 units (one per 16-row m-tile), single time tile.
 __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const float* __restrict__ bias, int lane,
                                            const HL (&xb)[1][2], f32x4 (&y)[1][4]) {
@@ -261,8 +278,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
-        load_unit(fb, ws); WS_ADVP(1024, 2048);                // Wv, pair p
-        const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g), bv = ldg4(W + L.bv + 16 * p + 4 * g);
+        if (S2S_ABL & 4096) { for (int i = 0; i < 4; ++i) fb[i] = fa[i]; } else load_unit(fb, ws);   // (4096: timing without this phase's loads)
+        WS_ADVP(1024, 2048);                                   // Wv, pair p
+        const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g);
+        const float bv = W[L.bv + 16 * p + c];                 // V comes out transposed: this lane's column is one feature
         __builtin_amdgcn_sched_barrier(0);
         // bias is added after the GEMM: the inline-asm split below must read results of compiler-visible
         // VALU instructions, never an MFMA accumulator directly (MFMA -> VALU read needs wait states)
@@ -271,10 +290,12 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
         mm_unit_h<NQ>(ak, fa, xb);
         __builtin_amdgcn_sched_barrier(0);
-        load_unit(fa, ws); WS_ADVP(1024, 2048);                // Wk, pair p+1 (after the last pair: Wq, pair 0)
+        if (!(S2S_ABL & 4096) || p == 3) load_unit(fa, ws);
+        WS_ADVP(1024, 2048);                                   // Wk, pair p+1 (after the last pair: Wq, pair 0)
         __builtin_amdgcn_sched_barrier(0);
-        mm_unit_h<NQ>(av, fb, xb);
-        const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // accumulator rows 4g..4g+3 = head, d0..d0+3
+        mm_unit_h_t<NQ>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
+        const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // K accumulator rows 4g..4g+3 = head, d0..d0+3
+        const int vrow = (2 * p + (c >> 3)) * 16 + (c & 7);    // V^T row of this lane's feature (hi; lo is 8 rows below)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int key = 16 * (qt0 + q) + c;
@@ -282,12 +303,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             split4(ak[q] + bk, one, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
-            split4(av[q] + bv, one, hi, lo);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Vl[(head * 16 + d0 + r) * G::VS + key] = hi[r];
-                Vl[(head * 16 + 8 + d0 + r) * G::VS + key] = lo[r];
-            }
+            split4(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
+            *reinterpret_cast<h4*>(Vl + vrow * G::VS + 16 * (qt0 + q) + 4 * g) = hi;
+            *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + 16 * (qt0 + q) + 4 * g) = lo;
         }
     }
     // ---- fc accumulator starts as bias + residual (layers.py:85-86)
