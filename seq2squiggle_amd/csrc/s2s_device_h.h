@@ -30,6 +30,16 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define S2S_ALWAYS_RESCALE 0
 #endif
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
+#ifndef S2S_NO_SB_ATT
+#define SB_ATT() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SB_ATT()
+#endif
+#ifndef S2S_NO_SB_GEMM
+#define SB_GEMM() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SB_GEMM()
+#endif
 #define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 struct HL { h8 hi, lo; };
@@ -178,7 +188,7 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
             if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
             va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         }
-        __builtin_amdgcn_sched_barrier(0);
+        SB_ATT();
         // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
         // beside the other's exponentials inside the same wave
         f32x4 s[NQ][HK];
@@ -282,17 +292,17 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         WS_ADVP(1024, 2048);                                   // Wv, pair p
         const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g);
         const float bv = W[L.bv + 16 * p + c];                 // V comes out transposed: this lane's column is one feature
-        __builtin_amdgcn_sched_barrier(0);
+        SB_GEMM();
         // bias is added after the GEMM: the inline-asm split below must read results of compiler-visible
         // VALU instructions, never an MFMA accumulator directly (MFMA -> VALU read needs wait states)
         f32x4 ak[NQ], av[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
         mm_unit_h<NQ>(ak, fa, xb);
-        __builtin_amdgcn_sched_barrier(0);
+        SB_GEMM();
         if (!(S2S_ABL & 4096) || p == 3) load_unit(fa, ws);
         WS_ADVP(1024, 2048);                                   // Wk, pair p+1 (after the last pair: Wq, pair 0)
-        __builtin_amdgcn_sched_barrier(0);
+        SB_GEMM();
         mm_unit_h_t<NQ>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
         const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // K accumulator rows 4g..4g+3 = head, d0..d0+3
         const int vrow = (2 * p + (c >> 3)) * 16 + (c & 7);    // V^T row of this lane's feature (hi; lo is 8 rows below)
@@ -333,12 +343,12 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
             if (pp == 0) { load_unit(fb, ws); WS_ADVP(1024, 8192); } else { load_unit(fa, ws); WS_ADVP(1024, 8192); }
             const f32x4 bq = ldg4(W + L.bq_nat + 16 * p + 4 * g);
-            __builtin_amdgcn_sched_barrier(0);
+            SB_GEMM();
             f32x4 qa[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) qa[q] = f32x4{0, 0, 0, 0};
             if (pp == 0) mm_unit_h<NQ>(qa, fa, xb); else mm_unit_h<NQ>(qa, fb, xb);
-            __builtin_amdgcn_sched_barrier(0);
+            SB_GEMM();
             // Q^T rows live 4 per lane group; the S MFMA wants all 8 d of a head in every lane
             // ([Q_hi | Q_lo | Q_hi | Q_lo] over the lane groups): re-layout through the wave's scratch
 #pragma unroll
@@ -396,7 +406,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
         for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q], one);
             load_unit(fb, ws); WS_ADVP(1024, 8192);                // Wfc(u), m-tiles 2-3
-        __builtin_amdgcn_sched_barrier(0);
+        SB_GEMM();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {        // unit = [mt a hi][mt a lo][mt b hi][mt b lo]
 #pragma unroll
@@ -412,9 +422,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wl, ob[q].hi, acc[q][mt]);
             }
             if (half == 0) {
-                __builtin_amdgcn_sched_barrier(0);
+                SB_GEMM();
                 load_unit(fa, ws); WS_ADVP(1024, 8192);        // next iteration's Wq (after the last: W1 unit 0)
-                __builtin_amdgcn_sched_barrier(0);
+                SB_GEMM();
             }
         }
     }
@@ -427,7 +437,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
     for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
     load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); WS_ADVP(2048, 16384);
-    __builtin_amdgcn_sched_barrier(0);
+    SB_GEMM();
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
     DIAG_STAMP(4);
     HL x1b[NQ][2];
@@ -451,9 +461,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
             load_unit(ring[(mt + 3) & 3], ws); WS_ADVP(1024, 16384);
-            __builtin_amdgcn_sched_barrier(0);
+            SB_GEMM();
             mm_unit_h<NQ>(t, ring[mt & 3], x1b);
-            __builtin_amdgcn_sched_barrier(0);
+            SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -468,9 +478,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
             load_unit(ring[(mt + 3) & 3], ws); WS_ADVP(1024, 16384);
-            __builtin_amdgcn_sched_barrier(0);
+            SB_GEMM();
             mm_unit_h<NQ>(t, ring[mt & 3], hb);
-            __builtin_amdgcn_sched_barrier(0);
+            SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
         }
