@@ -1,0 +1,16 @@
+#!/bin/bash
+# Everything profiles/rNN holds, in one GPU-box call: tools/profile_round.sh <tag>
+#   gpurun_out/<tag>/stats_{f16x3,f32}: rocprofv3 --kernel-trace --stats of bench.py --steps 3 (+ the bench line it printed)
+#   gpurun_out/<tag>/pmc_{f16x3,f32}:   the PMC passes of tools/pmc_run.sh
+#   gpurun_out/<tag>/bench_f16x3.json:  the plain default bench line (CPU baseline + end-to-end included)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+T=$1
+mkdir -p $R/gpurun_out/$T
+cd /tmp && export TMPDIR=/tmp
+for m in f16x3 f32; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats_$m -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode $m > $R/gpurun_out/$T/bench_${m}_under_rocprof.json 2> $R/gpurun_out/$T/stats_$m.err
+  bash $R/tools/pmc_run.sh $T/pmc_$m --mode $m
+done
+cd $R && python3 bench.py > gpurun_out/$T/bench_f16x3.json 2> gpurun_out/$T/bench_f16x3.err
+python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32 f16x3=gpurun_out/$T/pmc_f16x3 > gpurun_out/$T/pmc_summary.json
+ls gpurun_out/$T gpurun_out/$T/stats_f16x3
