@@ -11,6 +11,7 @@ are out of scope.
 import gzip
 import logging
 import os
+import math
 import random
 import sys
 from typing import Dict, Generator, Iterable, List, Tuple
@@ -123,6 +124,39 @@ def draw_expon_dis(mean, seed, total_len):
     return np.clip(sample, 1, total_len)
 
 
+def _mt19937_first_double(seeds: np.ndarray) -> np.ndarray:
+    """random_sample() of np.random.RandomState(seed) for a whole vector of integer seeds at once: init_genrand, the
+    twist of state words 0 and 1 (which only needs words 0-2, 397, 398) and the 53-bit double of the legacy generator."""
+    mt = np.empty((399, seeds.shape[0]), dtype=np.uint64)
+    mt[0] = seeds.astype(np.uint64) & 0xFFFFFFFF
+    for i in range(1, 399):
+        prev = mt[i - 1]
+        mt[i] = (1812433253 * (prev ^ (prev >> 30)) + i) & 0xFFFFFFFF
+
+    def twist(a, b, c):
+        y = (a & 0x80000000) | (b & 0x7FFFFFFF)
+        return c ^ (y >> 1) ^ np.where(y & 1, 0x9908B0DF, 0).astype(np.uint64)
+
+    def temper(y):
+        y = y ^ (y >> 11)
+        y = y ^ ((y << 7) & 0x9D2C5680)
+        y = y ^ ((y << 15) & 0xEFC60000)
+        return (y ^ (y >> 18)) & 0xFFFFFFFF
+
+    a = temper(twist(mt[0], mt[1], mt[397])) >> 5
+    b = temper(twist(mt[1], mt[2], mt[398])) >> 6
+    return (a.astype(np.float64) * 67108864.0 + b.astype(np.float64)) / 9007199254740992.0
+
+
+def draw_expon_dis_many(mean, seeds: np.ndarray, total_len) -> np.ndarray:
+    """draw_expon_dis for a vector of seeds, bit-identical to the per-seed scipy call (tests/test_sampler_cpu.py): scipy
+    seeds a fresh legacy RandomState per call and takes loc + scale * standard_exponential(), i.e. -log(1 - double)
+    with the C library's log (math.log; np.log may differ in the last bit)."""
+    e = np.array([-math.log(1.0 - x) for x in _mt19937_first_double(seeds)])
+    sample = ((213.98910256668592 + 6972.5319847131141 * e) * mean / 7106.0).astype(int)
+    return np.clip(sample, 1, total_len)
+
+
 _DISTR = {"beta": draw_beta_dis, "gamma": draw_gamma_dis, "expon": draw_expon_dis}
 _COMPLEMENT = str.maketrans("ATCG", "TAGC")
 
@@ -164,14 +198,25 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
     read set."""
     sampled_reads = []
     total_genome_len = sum(genome_lens)
+    # the first-try lengths of a block of reads in one vectorised pass (the per-seed scipy call costs ~100 us and is what
+    # the reference's sampler spends its time in); retries and the other distributions go through scipy one by one
+    fast = distr == "expon" and r > 0 and 0 <= seed and seed + num_seqs * (max_retries + 1) < 2 ** 32
+    block, block_lo = None, 0
     for read_i in range(num_seqs):
+        if fast and (block is None or read_i >= block_lo + len(block)):
+            block_lo = read_i
+            idx = np.arange(read_i, min(num_seqs, read_i + 8192), dtype=np.int64)
+            block = draw_expon_dis_many(r, seed + idx * (max_retries + 1), total_len)
         retries = 0
         while retries < max_retries:
             start_pos = random.randint(0, total_genome_len - 1)
             genome_index, start_index = get_genome_and_position(genome_lens, start_pos)
             genome = genome_seqs[genome_index]
             unique_seed = seed + read_i * (max_retries + 1) + retries
-            read_length = int(_DISTR[distr](r, unique_seed, total_len)) if r > 0 else len(genome)
+            if fast and retries == 0:
+                read_length = int(block[read_i - block_lo])
+            else:
+                read_length = int(_DISTR[distr](r, unique_seed, total_len)) if r > 0 else len(genome)
             read = genome[start_index:start_index + read_length]
             if profile.startswith("dna"):
                 read_strand = random.choice("+-")

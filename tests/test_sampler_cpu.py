@@ -53,6 +53,15 @@ def test_sampler_matches_reference_read_sets(name):
     assert total_l == int(g[name + "__total_l"])
 
 
+def test_vectorised_length_draws_equal_the_per_seed_scipy_call():
+    """draw_expon_dis_many re-implements RandomState(seed) + scipy's expon.rvs for a vector of seeds: bit-identical."""
+    seeds = np.concatenate([np.arange(0, 300), 42 + 21 * np.arange(2000), np.array([2 ** 31 - 1, 2 ** 32 - 1, 123456789])])
+    for mean in (5000, 150, 20000):
+        fast = U.draw_expon_dis_many(mean, seeds, 48502)
+        ref = np.array([int(U.draw_expon_dis(mean, int(sd), 48502)) for sd in seeds[::7]])
+        assert np.array_equal(fast[::7], ref)
+
+
 def test_sampler_argument_errors():
     cfg = {"max_dna_len": 16}
     with pytest.raises(ValueError):
