@@ -176,14 +176,17 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
 }
 
 // ================================================================================ decoder
+#ifndef DEC_WAVES
 #define DEC_WAVES 8
 #define DEC_NQ 2            // 16-column time tiles per wave: 8 waves x 2 x 16 = 256 >= 250
+#endif
+#define DEC_WPS (DEC_WAVES / 4)   // waves per SIMD
 #define DEC_NKT 16
 static constexpr int DEC_LDS_F32 = AttnLds<DEC_NKT>::BYTES;
 static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>::BYTES;
 
 template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h)
-__global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel(
+__global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
     const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
     const float* __restrict__ ws_sigma, const int* __restrict__ dur, int n_chunks, long long first_chunk, ParamsDev P,
     const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
