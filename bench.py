@@ -115,8 +115,8 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
     parity = {"chunks": n, "signal_mae_pa": float(np.abs(y - r).mean()), "signal_max_abs_pa": float(np.abs(y - r).max()),
               "dwell_indices_equal": bool(np.array_equal(got["dur"].cpu().numpy(), ref["dur"].numpy())),
               "zero_pattern_equal": bool(np.array_equal(y == 0, r == 0)), "tolerance_mae_pa": 1e-4}
-    return {"value": done * 250 / el, "unit": "samples/s", "cores": len(os.sched_getaffinity(0)), "parity": parity,
-            "torch_threads": torch.get_num_threads(), "kind": "port",
+    return {"value": done * 250 / el, "unit": "samples/s", "cores": torch.get_num_threads(), "parity": parity,
+            "host_logical_cpus": len(os.sched_getaffinity(0)), "kind": "port",
             "reads_per_sec": done / CHUNKS_PER_READ / el,
             "sample": f"{done} chunks (batches of 1024, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
 
