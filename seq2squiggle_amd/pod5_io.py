@@ -1,0 +1,269 @@
+"""Native POD5 container writer -- UNVALIDATED against the pod5 library.
+
+The reference writes POD5 through ONT's `pod5` package (signal_io.py:175-287), which this image lacks, so the
+container below follows the published format description (pod5-file-format: docs/SPECIFICATION.md, docs/tables/*.toml,
+c++/pod5_format/footer.fbs) from the author's knowledge of it, with pyarrow for the embedded Arrow IPC files and a
+hand-written flatbuffer for the footer.  What IS pinned: the per-read record content (ids, calibration, int16 samples,
+run info) against what the reference's POD5Writer hands to the library (tests/golden/pod5_records.npz), and a round
+trip through the reader in this file.  What is NOT: acceptance by libpod5 / dorado.  Signals are stored uncompressed
+(`large_list<int16>`; the VBZ codec needs zstd, also absent).
+
+Layout:  signature | marker | signal table | pad8 | marker | run-info table | pad8 | marker | reads table | pad8 |
+         marker | "FOOTER\\0\\0" | flatbuffer (size multiple of 8) | int64 footer length | marker | signature
+"""
+import datetime as _dt
+import io
+import struct
+import uuid
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+SIGNATURE = b"\x8bPOD\r\n\x1a\n"
+FOOTER_MAGIC = b"FOOTER\x00\x00"
+POD5_VERSION = "0.1.0"          # reads-table spec v3 (flattened columns), before open_pore_level was added
+SOFTWARE = "seq2squiggle_amd"
+SIGNAL_CHUNK = 102400           # samples per signal-table row (libpod5's default)
+SIGNAL_BATCH_ROWS, READ_BATCH_ROWS = 100, 1000    # fixed batch sizes: readers index rows as batch = row // size
+CT_READS, CT_SIGNAL, CT_READ_ID_INDEX, CT_OTHER_INDEX, CT_RUN_INFO = 0, 1, 2, 3, 4
+END_REASONS = ["unknown", "mux_change", "unblock_mux_change", "data_service_unblock_mux_change", "signal_positive",
+               "signal_negative"]
+
+RUN_INFO_FIELDS = ("acquisition_id", "acquisition_start_time", "adc_max", "adc_min", "context_tags", "experiment_name",
+                   "flow_cell_id", "flow_cell_product_code", "protocol_name", "protocol_run_id", "protocol_start_time",
+                   "sample_id", "sample_rate", "sequencing_kit", "sequencer_position", "sequencer_position_type", "software",
+                   "system_name", "system_type", "tracking_id")
+
+
+def _pa():
+    import pyarrow as pa
+    return pa
+
+
+# ------------------------------------------------------------------------------------------------ footer flatbuffer
+def build_footer(file_identifier: str, software: str, version: str, files: Sequence[tuple]) -> bytes:
+    """footer.fbs: table Footer { file_identifier, software, pod5_version: string; contents: [EmbeddedFile]; }
+    table EmbeddedFile { offset, length: int64; format: Format(short) = FeatherV2; content_type: ContentType(short); }
+    Built front to back: every uoffset points forward, vtables sit in front of their tables."""
+    buf = bytearray(8)                                   # [0] root uoffset, [4] padding
+
+    def align(n):
+        while len(buf) % n:
+            buf.append(0)
+
+    def string(s):
+        align(4)
+        pos = len(buf)
+        b = s.encode()
+        buf.extend(struct.pack("<I", len(b)) + b + b"\x00")
+        return pos
+
+    # root vtable + table
+    align(4)
+    vt = len(buf)
+    buf.extend(struct.pack("<HHHHHH", 12, 20, 4, 8, 12, 16))
+    root = len(buf)
+    buf.extend(struct.pack("<i", root - vt) + bytes(16))
+    struct.pack_into("<I", buf, 0, root)
+    strings = [string(file_identifier), string(software), string(version)]
+    for i, pos in enumerate(strings):
+        struct.pack_into("<I", buf, root + 4 + 4 * i, pos - (root + 4 + 4 * i))
+    # contents vector
+    align(4)
+    vec = len(buf)
+    struct.pack_into("<I", buf, root + 16, vec - (root + 16))
+    buf.extend(struct.pack("<I", len(files)) + bytes(4 * len(files)))
+    # one vtable shared by all EmbeddedFile tables: soffset at 0, offset at 8, length at 16, format at 24, type at 26
+    align(2)
+    evt = len(buf)
+    buf.extend(struct.pack("<HHHHHH", 12, 28, 8, 16, 24, 26))
+    for i, (offset, length, content_type) in enumerate(files):
+        align(8)
+        t = len(buf)
+        buf.extend(struct.pack("<iiqqhh", t - evt, 0, offset, length, 0, content_type))
+        struct.pack_into("<I", buf, vec + 4 + 4 * i, t - (vec + 4 + 4 * i))
+    align(8)
+    return bytes(buf)
+
+
+def parse_footer(fb: bytes) -> dict:
+    def u32(p):
+        return struct.unpack_from("<I", fb, p)[0]
+
+    def field(table, idx):
+        vt = table - struct.unpack_from("<i", fb, table)[0]
+        vsize = struct.unpack_from("<H", fb, vt)[0]
+        if 4 + 2 * idx >= vsize:
+            return 0
+        off = struct.unpack_from("<H", fb, vt + 4 + 2 * idx)[0]
+        return table + off if off else 0
+
+    def string(p):
+        p += u32(p)
+        return fb[p + 4: p + 4 + u32(p)].decode()
+
+    root = u32(0)
+    out = {"file_identifier": string(field(root, 0)), "software": string(field(root, 1)),
+           "pod5_version": string(field(root, 2)), "contents": []}
+    v = field(root, 3)
+    v += u32(v)
+    for i in range(u32(v)):
+        p = v + 4 + 4 * i
+        t = p + u32(p)
+        get = lambda idx, fmt, default=0: struct.unpack_from(fmt, fb, field(t, idx))[0] if field(t, idx) else default
+        out["contents"].append({"offset": get(0, "<q"), "length": get(1, "<q"), "format": get(2, "<h"),
+                                "content_type": get(3, "<h")})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ arrow tables
+def _uuid_field(pa):
+    return pa.field("read_id", pa.binary(16), nullable=False,
+                    metadata={"ARROW:extension:name": "minknow.uuid", "ARROW:extension:metadata": ""})
+
+
+def _ipc_bytes(pa, schema, batches) -> bytes:
+    sink = io.BytesIO()
+    with pa.ipc.new_file(sink, schema) as w:
+        for b in batches:
+            w.write_batch(b)
+    return sink.getvalue()
+
+
+def _signal_table(pa, meta, reads) -> tuple:
+    schema = pa.schema([_uuid_field(pa), pa.field("signal", pa.large_list(pa.int16())), pa.field("samples", pa.uint32())],
+                       metadata=meta)
+    ids, sigs, counts, rows_of = [], [], [], []
+    for r in reads:
+        raw = np.ascontiguousarray(r["signal"], dtype=np.int16)
+        mine = []
+        for lo in range(0, max(len(raw), 1), SIGNAL_CHUNK):
+            part = raw[lo: lo + SIGNAL_CHUNK]
+            mine.append(len(ids))
+            ids.append(r["read_id"].bytes)
+            sigs.append(part)
+            counts.append(len(part))
+        rows_of.append(mine)
+    batches = []
+    for lo in range(0, len(ids), SIGNAL_BATCH_ROWS):
+        hi = min(len(ids), lo + SIGNAL_BATCH_ROWS)
+        flat = np.concatenate(sigs[lo:hi]) if hi > lo else np.zeros(0, np.int16)
+        offs = np.concatenate([[0], np.cumsum(counts[lo:hi])]).astype(np.int64)
+        batches.append(pa.record_batch([pa.array(ids[lo:hi], pa.binary(16)),
+                                        pa.LargeListArray.from_arrays(pa.array(offs, pa.int64()), pa.array(flat, pa.int16())),
+                                        pa.array(counts[lo:hi], pa.uint32())], schema=schema))
+    return _ipc_bytes(pa, schema, batches), rows_of
+
+
+def _ms(t):
+    if isinstance(t, _dt.datetime):
+        return int(t.replace(tzinfo=t.tzinfo or _dt.timezone.utc).timestamp() * 1000)
+    return int(t)
+
+
+def _run_info_table(pa, meta, run_infos: List[dict]) -> bytes:
+    ts, s, m = pa.timestamp("ms", "UTC"), pa.utf8(), pa.map_(pa.utf8(), pa.utf8())
+    types = {"acquisition_start_time": ts, "protocol_start_time": ts, "adc_max": pa.int16(), "adc_min": pa.int16(),
+             "sample_rate": pa.uint16(), "context_tags": m, "tracking_id": m}
+    schema = pa.schema([pa.field(n, types.get(n, s)) for n in RUN_INFO_FIELDS], metadata=meta)
+    cols = []
+    for n in RUN_INFO_FIELDS:
+        t = types.get(n, s)
+        vals = [ri[n] for ri in run_infos]
+        if t == ts:
+            vals = [_ms(v) for v in vals]
+        elif t == m:
+            vals = [sorted(dict(v).items()) for v in vals]
+        cols.append(pa.array(vals, t))
+    return _ipc_bytes(pa, schema, [pa.record_batch(cols, schema=schema)])
+
+
+def _reads_table(pa, meta, reads, rows_of, run_ids: List[str], pore_types: List[str]) -> bytes:
+    f32, d = pa.float32(), lambda: pa.dictionary(pa.int16(), pa.utf8())
+    fields = [_uuid_field(pa), pa.field("signal", pa.list_(pa.uint64())), pa.field("read_number", pa.uint32()),
+              pa.field("start", pa.uint64()), pa.field("median_before", f32), pa.field("num_minknow_events", pa.uint64()),
+              pa.field("tracked_scaling_scale", f32), pa.field("tracked_scaling_shift", f32),
+              pa.field("predicted_scaling_scale", f32), pa.field("predicted_scaling_shift", f32),
+              pa.field("num_reads_since_mux_change", pa.uint32()), pa.field("time_since_mux_change", f32),
+              pa.field("num_samples", pa.uint64()), pa.field("channel", pa.uint16()), pa.field("well", pa.uint8()),
+              pa.field("pore_type", d()), pa.field("calibration_offset", f32), pa.field("calibration_scale", f32),
+              pa.field("end_reason", d()), pa.field("end_reason_forced", pa.bool_()), pa.field("run_info", d())]
+    schema = pa.schema(fields, metadata=meta)
+    pore_dict, end_dict, run_dict = pa.array(pore_types, pa.utf8()), pa.array(END_REASONS, pa.utf8()), pa.array(run_ids, pa.utf8())
+    nan = float("nan")
+    batches = []
+    for lo in range(0, len(reads), READ_BATCH_ROWS):
+        part, rows = reads[lo: lo + READ_BATCH_ROWS], rows_of[lo: lo + READ_BATCH_ROWS]
+        n = len(part)
+        col = lambda key, t: pa.array([r[key] for r in part], t)
+        const = lambda v, t: pa.array([v] * n, t)
+        dic = lambda idx, dictionary: pa.DictionaryArray.from_arrays(pa.array(idx, pa.int16()), dictionary)
+        batches.append(pa.record_batch([
+            pa.array([r["read_id"].bytes for r in part], pa.binary(16)), pa.array(rows, pa.list_(pa.uint64())),
+            col("read_number", pa.uint32()), col("start_sample", pa.uint64()), col("median_before", f32),
+            const(0, pa.uint64()), const(nan, f32), const(nan, f32), const(nan, f32), const(nan, f32),
+            const(0, pa.uint32()), const(0.0, f32), pa.array([len(r["signal"]) for r in part], pa.uint64()),
+            col("channel", pa.uint16()), col("well", pa.uint8()), dic([pore_types.index(r["pore_type"]) for r in part], pore_dict),
+            col("calibration_offset", f32), col("calibration_scale", f32),
+            dic([END_REASONS.index(r["end_reason"]) for r in part], end_dict), col("end_reason_forced", pa.bool_()),
+            dic([run_ids.index(r["run_info"]["acquisition_id"]) for r in part], run_dict)], schema=schema))
+    return _ipc_bytes(pa, schema, batches)
+
+
+# ------------------------------------------------------------------------------------------------ file
+def write_pod5(path: str, reads: List[dict], file_identifier: uuid.UUID = None, section_marker: bytes = None) -> None:
+    """reads: dicts with read_id (uuid.UUID), signal (int16 array), read_number, start_sample, median_before, channel,
+    well, pore_type, calibration_offset, calibration_scale, end_reason (a name from END_REASONS), end_reason_forced,
+    run_info (dict with RUN_INFO_FIELDS; reads may share one)."""
+    pa = _pa()
+    file_identifier = file_identifier or uuid.uuid4()
+    marker = section_marker or uuid.uuid4().bytes
+    meta = {"MINKNOW:file_identifier": str(file_identifier), "MINKNOW:software": SOFTWARE, "MINKNOW:pod5_version": POD5_VERSION}
+    run_infos, run_ids = [], []
+    for r in reads:
+        if r["run_info"]["acquisition_id"] not in run_ids:
+            run_ids.append(r["run_info"]["acquisition_id"])
+            run_infos.append(r["run_info"])
+    pore_types = sorted({r["pore_type"] for r in reads})
+    signal_bytes, rows_of = _signal_table(pa, meta, reads)
+    tables = [(CT_SIGNAL, signal_bytes), (CT_RUN_INFO, _run_info_table(pa, meta, run_infos)),
+              (CT_READS, _reads_table(pa, meta, reads, rows_of, run_ids, pore_types))]
+    with open(path, "xb") as f:                      # like pod5.Writer: refuses to overwrite
+        f.write(SIGNATURE + marker)
+        entries = []
+        for ct, data in tables:
+            entries.append((f.tell(), len(data), ct))
+            f.write(data + bytes(-len(data) % 8) + marker)
+        fb = build_footer(str(file_identifier), SOFTWARE, POD5_VERSION, entries)
+        f.write(FOOTER_MAGIC + fb + struct.pack("<q", len(fb)) + marker + SIGNATURE)
+
+
+def read_pod5(path: str) -> dict:
+    """Reader of the files written above (tests / round trip): -> dict(footer, run_info rows, reads with their signal)."""
+    pa = _pa()
+    data = open(path, "rb").read()
+    if data[:8] != SIGNATURE or data[-8:] != SIGNATURE:
+        raise ValueError("not a POD5 file: bad signature")
+    marker = data[8:24]
+    if data[-24:-8] != marker:
+        raise ValueError("section markers differ")
+    flen = struct.unpack_from("<q", data, len(data) - 32)[0]
+    fstart = len(data) - 32 - flen
+    if data[fstart - 8: fstart] != FOOTER_MAGIC:
+        raise ValueError("footer magic not found")
+    footer = parse_footer(data[fstart: fstart + flen])
+    tabs = {}
+    for e in footer["contents"]:
+        end = e["offset"] + e["length"]
+        if data[end + (-e["length"] % 8): end + (-e["length"] % 8) + 16] != marker:
+            raise ValueError("embedded file is not followed by the section marker")
+        tabs[e["content_type"]] = pa.ipc.open_file(io.BytesIO(data[e["offset"]: end])).read_all()
+    sig, reads_t, run_t = tabs[CT_SIGNAL], tabs[CT_READS], tabs[CT_RUN_INFO]
+    sig_rows = sig.column("signal").to_pylist()
+    reads = []
+    for row in reads_t.to_pylist():
+        raw = np.concatenate([np.asarray(sig_rows[i], np.int16) for i in row["signal"]]) if row["signal"] else np.zeros(0, np.int16)
+        row = dict(row, read_id=uuid.UUID(bytes=row["read_id"]), signal=raw)
+        reads.append(row)
+    return {"footer": footer, "schema_metadata": {k.decode(): v.decode() for k, v in reads_t.schema.metadata.items()},
+            "run_info": run_t.to_pylist(), "reads": reads, "signal_rows": sig.num_rows}

@@ -1,4 +1,4 @@
-"""SLOW5 / BLOW5 writers for the predict path.
+"""SLOW5 / BLOW5 / POD5 writers for the predict path.
 
 Reference: signal_io.py:62-172 (BLOW5Writer on pyslow5) and 175-282 (POD5Writer on pod5).  Neither
 library exists in this image, so the SLOW5 ASCII and BLOW5 binary encodings (slow5 specification
@@ -10,8 +10,8 @@ Deviations from the reference, on purpose:
     `idx` at every export batch and so writes duplicate `indexed_uuid`s, signal_io.py:123,145);
   * BLOW5 records are zlib-compressed with uncompressed int16 signal (pyslow5's default is zlib +
     svb-zd); both are valid BLOW5, the file is larger.
-  * POD5 is not written yet (the reference itself recommends BLOW5 + blue_crab for large runs,
-    inference.py:72-79).
+  * POD5 goes through the native container writer of pod5_io.py: record content pinned against the reference,
+    container unvalidated against libpod5, samples uncompressed (no zstd here for VBZ).
 """
 import logging
 import os
@@ -262,9 +262,66 @@ def read_slow5(path):
 
 
 class POD5Writer:
-    """Placeholder with the reference's constructor signature (signal_io.py:175-199)."""
+    """The reference's POD5Writer (signal_io.py:175-287) on the native container writer of pod5_io.py.  The records
+    (ids, calibration, int16 samples, run info) are pinned against the reference; the container is UNVALIDATED against
+    libpod5 (see pod5_io.py) and stores uncompressed samples."""
 
     def __init__(self, filename, profile, ideal_mode, profile_name, preserve_read_ids):
-        raise NotImplementedError("POD5 output is not available in this build (no pod5 library, native writer pending); "
-                                  "write .blow5/.slow5 and convert with blue_crab, as the reference recommends for "
-                                  "large runs")
+        self.filename = str(filename)
+        self.profile = profile
+        self.ideal_mode = ideal_mode
+        self.profile_name = profile_name
+        self.preserve_read_ids = preserve_read_ids
+        self.signals = None
+        self.dac = None
+        self.median_before = float(profile["median_before_mean"])
+        self.median_before_std = float(profile["median_before_std"])
+        self.offset = float(profile["offset_mean"])
+        self.offset_std = float(profile["offset_std"])
+        self.digitisation = float(profile["digitisation"])
+        self.signal_range = float(profile["range"])
+        self.sample_rate = float(profile["sample_rate"])
+        self.start_time = 0
+
+    def run_info(self) -> dict:
+        """signal_io.py:210-231."""
+        seq_kit, flow_cell = get_seq_kit_and_flow_cell(self.profile_name)
+        now = datetime.now()
+        return dict(acquisition_id="", acquisition_start_time=now, adc_max=4095, adc_min=-4096, context_tags={},
+                    experiment_name="", flow_cell_id="", flow_cell_product_code=flow_cell, protocol_name="",
+                    protocol_run_id="", protocol_start_time=now, sample_id="test", sample_rate=int(self.sample_rate),
+                    sequencing_kit=seq_kit, sequencer_position="", sequencer_position_type="", software="", system_name="",
+                    system_type="", tracking_id={})
+
+    def records(self) -> list:
+        """One dict per non-empty read, with what the reference passes to pod5.Read (signal_io.py:235-281)."""
+        rna = self.profile_name.startswith("rna")
+        run_info = self.run_info()
+        recs = []
+        for idx, (read_id, signal) in enumerate(self.signals.items()):
+            if len(signal) == 0:
+                logger.debug("Empty signal, skipping {}".format(read_id))
+                continue
+            if self.ideal_mode:
+                median_before_value, offset_value = self.median_before, self.offset
+            else:
+                median_before_value = np.random.normal(self.median_before, self.median_before_std)
+                offset_value = np.random.normal(self.offset, self.offset_std)
+            if self.dac is not None and read_id in self.dac:
+                raw = np.asarray(self.dac[read_id], dtype=np.int16)
+            else:
+                sig = signal.detach().cpu().numpy() if hasattr(signal, "detach") else np.asarray(signal)
+                raw = signal_to_dac(sig, self.digitisation, self.signal_range, self.offset, rna)
+            rid = uuid.uuid5(uuid.NAMESPACE_DNS, read_id) if self.preserve_read_ids else indexed_uuid(idx + 1)
+            recs.append(dict(read_id=rid, signal=raw, read_number=idx, start_sample=0, median_before=median_before_value,
+                             channel=123, well=3, pore_type="not_set", calibration_offset=offset_value,
+                             calibration_scale=self.signal_range / self.digitisation, end_reason="signal_positive",
+                             end_reason_forced=False, run_info=run_info))
+        return recs
+
+    def save(self):
+        if self.signals is None:
+            logger.warning("POD5 was not exported. No signals were found")
+            raise ValueError("POD5 was not exported. No signals were found")
+        from . import pod5_io
+        pod5_io.write_pod5(self.filename, self.records())

@@ -154,3 +154,25 @@ def test_inference_run_and_cli(tmp_path):
                       predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None, bps=None, digitisation=None,
                       range_val=None, offset_mean=None, offset_std=None, median_before_mean=None, median_before_std=None,
                       min_noise=0.0, min_duration=3, min_read_len=30, preserve_read_ids=True, seed=1)
+
+
+def test_cli_pod5_output_equals_blow5_output(tmp_path):
+    """`-o x.pod5` (reference flow: everything kept until the end, one POD5Writer.save) holds the same int16 samples as
+    the streaming .blow5 run of the same command; read ids are the uuid5 of the FASTA names (signal_io.py:262)."""
+    import uuid
+    from seq2squiggle_amd import pod5_io
+    outs = {}
+    for ext in (".pod5", ".blow5"):
+        out = tmp_path / ("o" + ext)
+        r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict", FASTA, "--read-input", "-o", str(out), "-m",
+                            os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--preserve-read-ids", "--seed", "5"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[ext] = out
+    d = pod5_io.read_pod5(str(outs[".pod5"]))
+    _, recs = signal_io.read_blow5(str(outs[".blow5"]))
+    assert len(d["reads"]) == len(recs) > 0
+    for p, b in zip(d["reads"], recs):
+        assert p["read_id"] == uuid.uuid5(uuid.NAMESPACE_DNS, b["read_id"])
+        assert np.array_equal(p["signal"], b["signal"])
+        assert abs(p["calibration_scale"] - b["range"] / b["digitisation"]) < 1e-6

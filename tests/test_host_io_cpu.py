@@ -64,8 +64,108 @@ def test_writer_ids_rna_and_errors(tmp_path):
     assert signal_io.get_seq_kit_and_flow_cell("dna-r9-min") == ("SQK-LSK109", "FLO-MIN110")
     with pytest.raises(ValueError):
         signal_io.get_seq_kit_and_flow_cell("dna-r7")
-    with pytest.raises(NotImplementedError):
-        signal_io.POD5Writer("x.pod5", p, True, "rna-004-prom", False)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_pod5_records_match_reference_writer(tmp_path, case):
+    """POD5Writer on the reference's per-read pA signals: every value the reference's POD5Writer.save hands to the pod5
+    library (recorded by tools/make_goldens.py pod5 -> pod5_records.npz) comes back out of the written file."""
+    import json
+    from seq2squiggle_amd import pod5_io
+    g = load_npz("pod5_records.npz")
+    tag, prof, ideal, preserve = [str(x) for x in g[f"case{case}__args"]]
+    sig = load_npz(f"signals_{tag}.npz")
+    order = [str(x) for x in sig["read_order"]]
+    path = tmp_path / "o.pod5"
+    w = signal_io.POD5Writer(path, U.get_profile(prof), ideal == "True", prof, preserve == "True")
+    with pytest.raises(ValueError):
+        w.save()
+    w.signals = {rid: torch.from_numpy(sig["sig__" + rid]) for rid in order}
+    w.save()
+    with pytest.raises(FileExistsError):             # like pod5.Writer: no appending (inference.py:71-79 exports once)
+        w.save()
+    d = pod5_io.read_pod5(str(path))
+    assert [str(r["read_id"]) for r in d["reads"]] == [str(x) for x in g[f"case{case}__read_ids"]]
+    meta = g[f"case{case}__meta"]
+    for i, r in enumerate(d["reads"]):
+        assert np.array_equal(r["signal"], g[f"case{case}__raw{i}"]) and r["num_samples"] == len(r["signal"])
+        off, scale, mb, num, start, channel, well, reason, forced = meta[i]
+        assert (r["calibration_offset"], r["calibration_scale"], r["median_before"]) == \
+               (np.float32(off), np.float32(scale), np.float32(mb))
+        assert (r["read_number"], r["start"], r["channel"], r["well"]) == (num, start, channel, well)
+        assert r["end_reason"] == pod5_io.END_REASONS[int(reason)] == str(g[f"case{case}__end_reason"]).lower()
+        assert r["end_reason_forced"] == bool(forced) and r["pore_type"] == str(g[f"case{case}__pore_type"])
+    ref_ri = json.loads(str(g[f"case{case}__run_info"]))
+    (ri,) = d["run_info"]
+    for k, v in ref_ri.items():
+        if v == "<datetime>":
+            assert ri[k] is not None
+        elif isinstance(v, dict):
+            assert dict(ri[k]) == v
+        else:
+            assert ri[k] == v, k
+    assert set(ri) == set(pod5_io.RUN_INFO_FIELDS)
+
+
+def test_pod5_container_layout(tmp_path):
+    """Signature, section markers, 8-byte padding, footer magic/length, flatbuffer footer (parsed by hand here, field by
+    field, independently of pod5_io.parse_footer) and the embedded Arrow files' schema metadata."""
+    import io, struct, uuid, datetime
+    import pyarrow as pa
+    from seq2squiggle_amd import pod5_io as P
+    ri = dict(zip(P.RUN_INFO_FIELDS, [""] * len(P.RUN_INFO_FIELDS)))
+    ri.update(acquisition_start_time=datetime.datetime(2024, 1, 2, 3, 4, 5), protocol_start_time=0, adc_max=4095, adc_min=-4096,
+              sample_rate=5000, context_tags={"k": "v"}, tracking_id={})
+    rng = np.random.default_rng(0)
+    lens = [10, 2 * P.SIGNAL_CHUNK + 7, 1] + [50] * 250                # > SIGNAL_BATCH_ROWS rows, one multi-row read
+    reads = [dict(read_id=uuid.UUID(int=i + 1), signal=rng.integers(-4096, 4096, n).astype(np.int16), read_number=i,
+                  start_sample=0, median_before=200.0, channel=1, well=2, pore_type="not_set", calibration_offset=-3.0,
+                  calibration_scale=0.5, end_reason="signal_positive", end_reason_forced=False, run_info=ri)
+             for i, n in enumerate(lens)]
+    path = str(tmp_path / "c.pod5")
+    marker, ident = bytes(range(16)), uuid.UUID(int=7)
+    P.write_pod5(path, reads, file_identifier=ident, section_marker=marker)
+    data = open(path, "rb").read()
+    assert data[:8] == data[-8:] == b"\x8bPOD\r\n\x1a\n" and data[8:24] == data[-24:-8] == marker
+    flen = struct.unpack_from("<q", data, len(data) - 32)[0]
+    fb = data[len(data) - 32 - flen: len(data) - 32]
+    assert flen % 8 == 0 and data[len(data) - 32 - flen - 8: len(data) - 32 - flen] == b"FOOTER\x00\x00"
+    # flatbuffer by hand: root table -> vtable -> 4 fields
+    root = struct.unpack_from("<I", fb, 0)[0]
+    vt = root - struct.unpack_from("<i", fb, root)[0]
+    vsize, tsize, *offs = struct.unpack_from("<HHHHHH", fb, vt)
+    assert vsize == 12 and all(0 < o < tsize for o in offs)
+
+    def fb_string(pos):
+        pos += struct.unpack_from("<I", fb, pos)[0]
+        n = struct.unpack_from("<I", fb, pos)[0]
+        assert fb[pos + 4 + n] == 0 and pos % 4 == 0
+        return fb[pos + 4: pos + 4 + n].decode()
+    assert [fb_string(root + o) for o in offs[:3]] == [str(ident), P.SOFTWARE, P.POD5_VERSION]
+    vec = root + offs[3] + struct.unpack_from("<I", fb, root + offs[3])[0]
+    assert struct.unpack_from("<I", fb, vec)[0] == 3
+    seen = {}
+    for i in range(3):
+        t = vec + 4 + 4 * i + struct.unpack_from("<I", fb, vec + 4 + 4 * i)[0]
+        tv = t - struct.unpack_from("<i", fb, t)[0]
+        _, _, o_off, o_len, o_fmt, o_ct = struct.unpack_from("<HHHHHH", fb, tv)
+        assert (t + o_off) % 8 == 0 and (t + o_len) % 8 == 0
+        off, ln = struct.unpack_from("<q", fb, t + o_off)[0], struct.unpack_from("<q", fb, t + o_len)[0]
+        assert struct.unpack_from("<h", fb, t + o_fmt)[0] == 0
+        seen[struct.unpack_from("<h", fb, t + o_ct)[0]] = (off, ln)
+        assert off % 8 == 0 and data[off: off + 6] == b"ARROW1" and data[off + ln - 6: off + ln] == b"ARROW1"
+        assert data[off + ln + (-ln % 8): off + ln + (-ln % 8) + 16] == marker
+    assert set(seen) == {P.CT_READS, P.CT_SIGNAL, P.CT_RUN_INFO}
+    sig = pa.ipc.open_file(io.BytesIO(data[seen[P.CT_SIGNAL][0]: sum(seen[P.CT_SIGNAL])]))
+    assert sig.schema.metadata[b"MINKNOW:pod5_version"] == P.POD5_VERSION.encode()
+    assert sig.schema.field("read_id").metadata[b"ARROW:extension:name"] == b"minknow.uuid"
+    assert sig.schema.field("signal").type == pa.large_list(pa.int16())
+    sizes = [sig.get_batch(i).num_rows for i in range(sig.num_record_batches)]
+    assert all(n == P.SIGNAL_BATCH_ROWS for n in sizes[:-1]) and sum(sizes) == len(lens) + 2
+    d = P.read_pod5(path)
+    assert [len(r["signal"]) for r in d["reads"]] == lens and d["reads"][1]["signal"].tolist() == reads[1]["signal"].tolist()
+    assert d["reads"][1]["signal"].dtype == np.int16 and len(reads_rows := d["reads"][1]) and d["signal_rows"] == len(lens) + 2
+    assert d["run_info"][0]["acquisition_start_time"].year == 2024 and d["run_info"][0]["context_tags"] == [("k", "v")]
 
 
 def test_onehot_to_bases_equals_chunker():

@@ -410,8 +410,73 @@ def sampler_goldens():
     np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
 
 
+class _Rec:
+    """Stands in for pod5.RunInfo / Pore / Calibration / EndReason / Read: keeps the keyword arguments."""
+    def __init__(self, **kw):
+        self.kw = kw
+
+
+class _FakePod5Writer:
+    captured = []          # list of (path, [Read kwargs])
+
+    def __init__(self, path):
+        self.path, self.reads = str(path), []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        _FakePod5Writer.captured.append((self.path, self.reads))
+
+    def add_read(self, read):
+        self.reads.append(read)
+
+
+def pod5_goldens():
+    """What the reference's POD5Writer.save (signal_io.py:201-287) hands to the pod5 library, for the per-read pA
+    signals of signals_{k9,k6}.npz: the pod5 module is a recorder (the real library is not in the image)."""
+    import enum
+    import json
+    P5 = sys.modules["pod5"]
+    P5.RunInfo = P5.Pore = P5.Calibration = P5.EndReason = P5.Read = _Rec
+    P5.EndReasonEnum = enum.Enum("EndReasonEnum", "UNKNOWN MUX_CHANGE UNBLOCK_MUX_CHANGE DATA_SERVICE_UNBLOCK_MUX_CHANGE "
+                                                  "SIGNAL_POSITIVE SIGNAL_NEGATIVE", start=0)
+    P5.Writer = _FakePod5Writer
+    out = {}
+    cases = [("k9", "dna-r10-prom", True, True), ("k9", "dna-r10-prom", True, False), ("k6", "rna-004-min", True, True)]
+    for ci, (tag, prof, ideal, preserve) in enumerate(cases):
+        sig = np.load(os.path.join(OUT, f"signals_{tag}.npz"))
+        order = [str(x) for x in sig["read_order"]]
+        _FakePod5Writer.captured = []
+        w = RS.POD5Writer(f"/tmp/golden_{ci}.pod5", RU.get_profile(prof), ideal, prof, preserve)
+        w.signals = {rid: torch.from_numpy(sig["sig__" + rid]) for rid in order}
+        w.save()
+        (path, reads), = _FakePod5Writer.captured
+        key = f"case{ci}"
+        out[key + "__args"] = np.array([tag, prof, str(ideal), str(preserve)])
+        ri = reads[0].kw["run_info"].kw
+        out[key + "__run_info"] = np.array(json.dumps({k: (v if isinstance(v, (str, int, float, dict)) else "<datetime>")
+                                                        for k, v in ri.items()}, sort_keys=True))
+        out[key + "__read_ids"] = np.array([str(r.kw["read_id"]) for r in reads])
+        out[key + "__meta"] = np.array([[r.kw["calibration"].kw["offset"], r.kw["calibration"].kw["scale"],
+                                         r.kw["median_before"], r.kw["read_number"], r.kw["start_sample"],
+                                         r.kw["pore"].kw["channel"], r.kw["pore"].kw["well"],
+                                         int(r.kw["end_reason"].kw["reason"].value), int(r.kw["end_reason"].kw["forced"])]
+                                        for r in reads], np.float64)
+        out[key + "__pore_type"] = np.array(reads[0].kw["pore"].kw["pore_type"])
+        out[key + "__end_reason"] = np.array(reads[0].kw["end_reason"].kw["reason"].name)
+        for i, r in enumerate(reads):
+            out[f"{key}__raw{i}"] = np.asarray(r.kw["signal"])
+            assert r.kw["run_info"] is reads[0].kw["run_info"]
+        print(key, tag, prof, len(reads), "pod5 reads captured")
+    np.savez_compressed(os.path.join(OUT, "pod5_records.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["pod5"]:          # only the POD5 record goldens (they read the committed signals_*.npz)
+        pod5_goldens()
+        return
     sampler_goldens()
     chunker_goldens()
     profile_goldens()
@@ -425,6 +490,7 @@ def main():
         export_goldens(tag, m, cfg, names, x16, sg, z250, prof)
     pe = {"enc": RM.Encoder(base_config(9)).position_enc.numpy(), "dec": RM.Decoder(base_config(9)).position_enc.numpy()}
     np.savez_compressed(os.path.join(OUT, "position_enc.npz"), **pe)
+    pod5_goldens()
     print("goldens written to", OUT)
 
 
