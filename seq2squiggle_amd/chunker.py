@@ -82,7 +82,7 @@ def pack_reads(seqs: Sequence[str], k: int):
     base = np.concatenate([[0], np.cumsum(padded)])
     # one join instead of a per-read array copy; reads that yield no chunk (len < k) contribute nothing
     blob = b"".join((s_.encode("latin-1") + b"_" * int(padded[i] - lens[i])) if C[i] > 0 else b"" for i, s_ in enumerate(seqs))
-    flat = np.frombuffer(blob + b"_", dtype=np.uint8)
+    flat = np.frombuffer(bytearray(blob + b"_"), dtype=np.uint8)          # (bytearray: a writable buffer for torch.from_numpy)
     read_first = np.concatenate([[0], np.cumsum(C)]).astype(np.int32)
     within = np.arange(int(read_first[-1])) - np.repeat(read_first[:-1], C)          # chunk index inside its read
     chunk_start = np.repeat(base[:-1], C) + T_ENC * within

@@ -149,6 +149,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             pending.result()
     finally:
         io.shutdown(wait=True)
+        if hasattr(writer, "close"):               # POD5: run-info and reads tables, footer
+            writer.close()
     return total
 
 
@@ -192,7 +194,7 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     check_model(load_model, config)
 
     n_chunks = 0
-    if streaming and isinstance(writer, BLOW5Writer):
+    if streaming and hasattr(writer, "dac_records"):
         n_chunks = run_streaming(load_model, reads, writer, profile_dict, profile)
     else:
         for batch in iter_batches(reads, config["seq_kmer"], predict_batch_size, load_model.device):

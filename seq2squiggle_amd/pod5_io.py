@@ -130,29 +130,47 @@ def _ipc_bytes(pa, schema, batches) -> bytes:
     return sink.getvalue()
 
 
-def _signal_table(pa, meta, reads) -> tuple:
-    schema = pa.schema([_uuid_field(pa), pa.field("signal", pa.large_list(pa.int16())), pa.field("samples", pa.uint32())],
-                       metadata=meta)
-    ids, sigs, counts, rows_of = [], [], [], []
-    for r in reads:
-        raw = np.ascontiguousarray(r["signal"], dtype=np.int16)
-        mine = []
-        for lo in range(0, max(len(raw), 1), SIGNAL_CHUNK):
-            part = raw[lo: lo + SIGNAL_CHUNK]
-            mine.append(len(ids))
-            ids.append(r["read_id"].bytes)
-            sigs.append(part)
-            counts.append(len(part))
-        rows_of.append(mine)
-    batches = []
-    for lo in range(0, len(ids), SIGNAL_BATCH_ROWS):
-        hi = min(len(ids), lo + SIGNAL_BATCH_ROWS)
-        flat = np.concatenate(sigs[lo:hi]) if hi > lo else np.zeros(0, np.int16)
-        offs = np.concatenate([[0], np.cumsum(counts[lo:hi])]).astype(np.int64)
-        batches.append(pa.record_batch([pa.array(ids[lo:hi], pa.binary(16)),
-                                        pa.LargeListArray.from_arrays(pa.array(offs, pa.int64()), pa.array(flat, pa.int16())),
-                                        pa.array(counts[lo:hi], pa.uint32())], schema=schema))
-    return _ipc_bytes(pa, schema, batches), rows_of
+class _SubFile:
+    """File-like view for pyarrow's IPC writer: positions are relative to where the embedded file starts."""
+
+    def __init__(self, f):
+        self.f, self.base, self.closed = f, f.tell(), False
+
+    def write(self, b):
+        return self.f.write(b)
+
+    def tell(self):
+        return self.f.tell() - self.base
+
+    def flush(self):
+        self.f.flush()
+
+    def close(self):
+        self.closed = True
+
+    def writable(self):
+        return True
+
+    def readable(self):
+        return False
+
+    def seekable(self):
+        return False
+
+
+def _signal_schema(pa, meta):
+    return pa.schema([_uuid_field(pa), pa.field("signal", pa.large_list(pa.int16())), pa.field("samples", pa.uint32())],
+                     metadata=meta)
+
+
+def _signal_batch(pa, schema, rows):
+    """rows: (read_id bytes, int16 array) per signal-table row."""
+    counts = [len(r[1]) for r in rows]
+    flat = np.concatenate([r[1] for r in rows]) if rows else np.zeros(0, np.int16)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return pa.record_batch([pa.array([r[0] for r in rows], pa.binary(16)),
+                            pa.LargeListArray.from_arrays(pa.array(offs, pa.int64()), pa.array(flat, pa.int16())),
+                            pa.array(counts, pa.uint32())], schema=schema)
 
 
 def _ms(t):
@@ -202,7 +220,7 @@ def _reads_table(pa, meta, reads, rows_of, run_ids: List[str], pore_types: List[
             pa.array([r["read_id"].bytes for r in part], pa.binary(16)), pa.array(rows, pa.list_(pa.uint64())),
             col("read_number", pa.uint32()), col("start_sample", pa.uint64()), col("median_before", f32),
             const(0, pa.uint64()), const(nan, f32), const(nan, f32), const(nan, f32), const(nan, f32),
-            const(0, pa.uint32()), const(0.0, f32), pa.array([len(r["signal"]) for r in part], pa.uint64()),
+            const(0, pa.uint32()), const(0.0, f32), col("num_samples", pa.uint64()),
             col("channel", pa.uint16()), col("well", pa.uint8()), dic([pore_types.index(r["pore_type"]) for r in part], pore_dict),
             col("calibration_offset", f32), col("calibration_scale", f32),
             dic([END_REASONS.index(r["end_reason"]) for r in part], end_dict), col("end_reason_forced", pa.bool_()),
@@ -211,31 +229,85 @@ def _reads_table(pa, meta, reads, rows_of, run_ids: List[str], pore_types: List[
 
 
 # ------------------------------------------------------------------------------------------------ file
+class Pod5FileWriter:
+    """Streaming writer: the signal table is the first embedded file and grows batch by batch while reads arrive; the
+    per-read rows (about 100 B each) are kept until close(), which writes the run-info and reads tables and the footer.
+    Memory stays bounded by one signal batch, unlike the reference path (all reads in RAM until the end,
+    inference.py:72-79).
+
+    reads: dicts with read_id (uuid.UUID), signal (int16 array), read_number, start_sample, median_before, channel, well,
+    pore_type, calibration_offset, calibration_scale, end_reason (a name from END_REASONS), end_reason_forced, run_info
+    (dict with RUN_INFO_FIELDS; reads may share one)."""
+
+    def __init__(self, path: str, file_identifier: uuid.UUID = None, section_marker: bytes = None):
+        pa = self.pa = _pa()
+        self.file_identifier = file_identifier or uuid.uuid4()
+        self.marker = section_marker or uuid.uuid4().bytes
+        self.meta = {"MINKNOW:file_identifier": str(self.file_identifier), "MINKNOW:software": SOFTWARE,
+                     "MINKNOW:pod5_version": POD5_VERSION}
+        self.f = open(path, "xb")                     # like pod5.Writer: refuses to overwrite
+        self.f.write(SIGNATURE + self.marker)
+        self.entries = []
+        self._sig_start = self.f.tell()
+        self._sig_schema = _signal_schema(pa, self.meta)
+        self._sig_writer = pa.ipc.new_file(_SubFile(self.f), self._sig_schema)
+        self._pending, self._n_rows = [], 0           # signal rows not yet written; rows written + pending
+        self._reads, self._rows_of = [], []
+        self._run_infos, self._run_ids = [], []
+        self.closed = False
+
+    def add_reads(self, reads: Sequence[dict]) -> None:
+        for r in reads:
+            raw = np.ascontiguousarray(r["signal"], dtype=np.int16)
+            rows = []
+            for lo in range(0, max(len(raw), 1), SIGNAL_CHUNK):
+                rows.append(self._n_rows)
+                self._pending.append((r["read_id"].bytes, raw[lo: lo + SIGNAL_CHUNK]))
+                self._n_rows += 1
+            self._rows_of.append(rows)
+            if r["run_info"]["acquisition_id"] not in self._run_ids:
+                self._run_ids.append(r["run_info"]["acquisition_id"])
+                self._run_infos.append(r["run_info"])
+            self._reads.append({k: v for k, v in r.items() if k != "signal"} | {"num_samples": len(raw)})
+        while len(self._pending) >= SIGNAL_BATCH_ROWS:
+            self._sig_writer.write_batch(_signal_batch(self.pa, self._sig_schema, self._pending[:SIGNAL_BATCH_ROWS]))
+            del self._pending[:SIGNAL_BATCH_ROWS]
+
+    def _end_embedded(self, start, content_type):
+        n = self.f.tell() - start
+        self.entries.append((start, n, content_type))
+        self.f.write(bytes(-n % 8) + self.marker)
+
+    def close(self) -> None:
+        if self.closed:
+            return
+        self.closed = True
+        pa = self.pa
+        if self._pending:
+            self._sig_writer.write_batch(_signal_batch(pa, self._sig_schema, self._pending))
+            self._pending = []
+        self._sig_writer.close()
+        self._end_embedded(self._sig_start, CT_SIGNAL)
+        pore_types = sorted({r["pore_type"] for r in self._reads})
+        for ct, data in ((CT_RUN_INFO, _run_info_table(pa, self.meta, self._run_infos)),
+                         (CT_READS, _reads_table(pa, self.meta, self._reads, self._rows_of, self._run_ids, pore_types))):
+            start = self.f.tell()
+            self.f.write(data)
+            self._end_embedded(start, ct)
+        fb = build_footer(str(self.file_identifier), SOFTWARE, POD5_VERSION, self.entries)
+        self.f.write(FOOTER_MAGIC + fb + struct.pack("<q", len(fb)) + self.marker + SIGNATURE)
+        self.f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def write_pod5(path: str, reads: List[dict], file_identifier: uuid.UUID = None, section_marker: bytes = None) -> None:
-    """reads: dicts with read_id (uuid.UUID), signal (int16 array), read_number, start_sample, median_before, channel,
-    well, pore_type, calibration_offset, calibration_scale, end_reason (a name from END_REASONS), end_reason_forced,
-    run_info (dict with RUN_INFO_FIELDS; reads may share one)."""
-    pa = _pa()
-    file_identifier = file_identifier or uuid.uuid4()
-    marker = section_marker or uuid.uuid4().bytes
-    meta = {"MINKNOW:file_identifier": str(file_identifier), "MINKNOW:software": SOFTWARE, "MINKNOW:pod5_version": POD5_VERSION}
-    run_infos, run_ids = [], []
-    for r in reads:
-        if r["run_info"]["acquisition_id"] not in run_ids:
-            run_ids.append(r["run_info"]["acquisition_id"])
-            run_infos.append(r["run_info"])
-    pore_types = sorted({r["pore_type"] for r in reads})
-    signal_bytes, rows_of = _signal_table(pa, meta, reads)
-    tables = [(CT_SIGNAL, signal_bytes), (CT_RUN_INFO, _run_info_table(pa, meta, run_infos)),
-              (CT_READS, _reads_table(pa, meta, reads, rows_of, run_ids, pore_types))]
-    with open(path, "xb") as f:                      # like pod5.Writer: refuses to overwrite
-        f.write(SIGNATURE + marker)
-        entries = []
-        for ct, data in tables:
-            entries.append((f.tell(), len(data), ct))
-            f.write(data + bytes(-len(data) % 8) + marker)
-        fb = build_footer(str(file_identifier), SOFTWARE, POD5_VERSION, entries)
-        f.write(FOOTER_MAGIC + fb + struct.pack("<q", len(fb)) + marker + SIGNATURE)
+    with Pod5FileWriter(path, file_identifier, section_marker) as w:
+        w.add_reads(reads)
 
 
 def read_pod5(path: str) -> dict:

@@ -282,6 +282,7 @@ class POD5Writer:
         self.signal_range = float(profile["range"])
         self.sample_rate = float(profile["sample_rate"])
         self.start_time = 0
+        self._stream, self._stream_idx, self._stream_run_info = None, 0, None
 
     def run_info(self) -> dict:
         """signal_io.py:210-231."""
@@ -293,8 +294,21 @@ class POD5Writer:
                     sequencing_kit=seq_kit, sequencer_position="", sequencer_position_type="", software="", system_name="",
                     system_type="", tracking_id={})
 
+    def _record(self, idx, read_id, raw, run_info) -> dict:
+        """What the reference passes to pod5.Read for one read (signal_io.py:240-281)."""
+        if self.ideal_mode:
+            median_before_value, offset_value = self.median_before, self.offset
+        else:
+            median_before_value = np.random.normal(self.median_before, self.median_before_std)
+            offset_value = np.random.normal(self.offset, self.offset_std)
+        rid = uuid.uuid5(uuid.NAMESPACE_DNS, read_id) if self.preserve_read_ids else indexed_uuid(idx + 1)
+        return dict(read_id=rid, signal=raw, read_number=idx, start_sample=0, median_before=median_before_value,
+                    channel=123, well=3, pore_type="not_set", calibration_offset=offset_value,
+                    calibration_scale=self.signal_range / self.digitisation, end_reason="signal_positive",
+                    end_reason_forced=False, run_info=run_info)
+
     def records(self) -> list:
-        """One dict per non-empty read, with what the reference passes to pod5.Read (signal_io.py:235-281)."""
+        """One dict per non-empty read of `signals` (pA tensors; converted here like signal_io.py:246-253)."""
         rna = self.profile_name.startswith("rna")
         run_info = self.run_info()
         recs = []
@@ -302,26 +316,42 @@ class POD5Writer:
             if len(signal) == 0:
                 logger.debug("Empty signal, skipping {}".format(read_id))
                 continue
-            if self.ideal_mode:
-                median_before_value, offset_value = self.median_before, self.offset
-            else:
-                median_before_value = np.random.normal(self.median_before, self.median_before_std)
-                offset_value = np.random.normal(self.offset, self.offset_std)
             if self.dac is not None and read_id in self.dac:
                 raw = np.asarray(self.dac[read_id], dtype=np.int16)
             else:
                 sig = signal.detach().cpu().numpy() if hasattr(signal, "detach") else np.asarray(signal)
                 raw = signal_to_dac(sig, self.digitisation, self.signal_range, self.offset, rna)
-            rid = uuid.uuid5(uuid.NAMESPACE_DNS, read_id) if self.preserve_read_ids else indexed_uuid(idx + 1)
-            recs.append(dict(read_id=rid, signal=raw, read_number=idx, start_sample=0, median_before=median_before_value,
-                             channel=123, well=3, pore_type="not_set", calibration_offset=offset_value,
-                             calibration_scale=self.signal_range / self.digitisation, end_reason="signal_positive",
-                             end_reason_forced=False, run_info=run_info))
+            recs.append(self._record(idx, read_id, raw, run_info))
         return recs
 
     def save(self):
+        """The reference's one-shot export (everything in `signals`, a new file)."""
         if self.signals is None:
             logger.warning("POD5 was not exported. No signals were found")
             raise ValueError("POD5 was not exported. No signals were found")
         from . import pod5_io
         pod5_io.write_pod5(self.filename, self.records())
+
+    # ---- streaming path (inference.run_streaming): samples already int16 on the GPU, reads arrive in super-batches and
+    #      the signal table grows on disk, so memory stays bounded (the reference keeps every read in RAM, inference.py:72-79)
+    def dac_records(self, read_ids, dac: np.ndarray, offsets: np.ndarray) -> list:
+        if self._stream_run_info is None:
+            self._stream_run_info = self.run_info()
+        recs = []
+        for i, rid in enumerate(read_ids):
+            idx = self._stream_idx
+            self._stream_idx += 1
+            if offsets[i + 1] > offsets[i]:
+                recs.append(self._record(idx, rid, dac[offsets[i]:offsets[i + 1]], self._stream_run_info))
+        return recs
+
+    def write_records(self, recs) -> None:
+        if self._stream is None:
+            from . import pod5_io
+            self._stream = pod5_io.Pod5FileWriter(self.filename)
+        self._stream.add_reads(recs)
+
+    def close(self) -> None:
+        if self._stream is not None:
+            self._stream.close()
+            self._stream = None

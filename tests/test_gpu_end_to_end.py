@@ -66,7 +66,7 @@ def test_model_object_export_flow(tmp_path, mode, tag, profile_name):
     check_file(tmp_path / "o.blow5", exp, [n for _, n in reads])
 
 
-@pytest.mark.parametrize("ext", [".blow5", ".slow5"])
+@pytest.mark.parametrize("ext", [".blow5", ".slow5", ".pod5"])
 def test_streaming_path_equals_predict_step_path(tmp_path, ext):
     """run_streaming (GPU zero-strip + DAC, no per-chunk Python objects) writes the same file content as the
     reference-shaped predict_step / export_and_clear_results / writer.save() flow, samplers on, fixed seed."""
@@ -86,8 +86,19 @@ def test_streaming_path_equals_predict_step_path(tmp_path, ext):
                       export_every_n_samples=100, sample_rate=None, bps=None, digitisation=None, range_val=None,
                       offset_mean=None, offset_std=None, median_before_mean=None, median_before_std=None, min_noise=0.0,
                       min_duration=3, min_read_len=30, preserve_read_ids=True, seed=11, streaming=streaming)
-        outs.append((signal_io.read_slow5 if ext == ".slow5" else signal_io.read_blow5)(str(out))[1])
+        if ext == ".pod5":
+            from seq2squiggle_amd import pod5_io
+            outs.append(pod5_io.read_pod5(str(out))["reads"])
+        else:
+            outs.append((signal_io.read_slow5 if ext == ".slow5" else signal_io.read_blow5)(str(out))[1])
     a, b = outs
+    if ext == ".pod5":
+        import uuid
+        assert [r["read_id"] for r in a] == [r["read_id"] for r in b] == [uuid.uuid5(uuid.NAMESPACE_DNS, f"r{i}") for i in range(1, 7)]
+        for ra, rb in zip(a, b):
+            assert np.array_equal(ra["signal"], rb["signal"]) and ra["num_samples"] == rb["num_samples"] == len(ra["signal"])
+            assert ra["calibration_offset"] == rb["calibration_offset"] and ra["read_number"] == rb["read_number"]
+        return
     assert [r["read_id"] for r in a] == [r["read_id"] for r in b] == ["r1", "r2", "r3", "r4", "r5", "r6"]
     for ra, rb in zip(a, b):
         assert np.array_equal(ra["signal"], rb["signal"])
