@@ -433,10 +433,12 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
     // A weight unit feeds only 6*NQ MFMAs (~200 cycles) here, less than an L2 round trip, so the stream
     // runs three units ahead through a ring of four unit buffers (8 units per slice: slots repeat).
-    f32x4 ring[4][4];
+    // (the one-wave frontend workgroups hide latency with occupancy instead: one unit ahead, 32 registers less)
+    constexpr int RD = (NQ >= 2) ? 4 : 2, RM = RD - 1;               // ring depth; units in flight = RD - 1
+    f32x4 ring[RD][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
-    load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); WS_ADVP(2048, 16384);
+    if (RD == 4) { load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); WS_ADVP(2048, 16384); }
     SB_GEMM();
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
     DIAG_STAMP(4);
@@ -460,9 +462,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
-            load_unit(ring[(mt + 3) & 3], ws); WS_ADVP(1024, 16384);
+            load_unit(ring[(mt + RM) & RM], ws); WS_ADVP(1024, 16384);
             SB_GEMM();
-            mm_unit_h<NQ>(t, ring[mt & 3], x1b);
+            mm_unit_h<NQ>(t, ring[mt & RM], x1b);
             SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -477,9 +479,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
-            load_unit(ring[(mt + 3) & 3], ws); WS_ADVP(1024, 16384);
+            load_unit(ring[(mt + RM) & RM], ws); WS_ADVP(1024, 16384);
             SB_GEMM();
-            mm_unit_h<NQ>(t, ring[mt & 3], hb);
+            mm_unit_h<NQ>(t, ring[mt & RM], hb);
             SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
