@@ -81,7 +81,7 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
                   max_chunks: int = 32768) -> int:
     """The predict loop without per-chunk Python objects: whole reads are grouped into super-batches of about
     `max_chunks` chunks; per super-batch one H2D of the packed read bytes, s2s_predict_packed, s2s_export_reads
-    (zero-strip + int16 conversion on the GPU), one D2H of the packed int16 samples, then the writer.  Produces the
+    (zero-strip + int16 conversion on the GPU), one D2H of the packed int16 samples on a copy stream, then the writer.  Produces the
     same records as predict_step + export_and_clear_results + writer.save().
 
     Three stages overlap: while the GPU works on super-batch i the host samples/packs i+1, and a writer thread
@@ -94,7 +94,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     total = 0
     io = ThreadPoolExecutor(max_workers=1)
     pending = None            # the writer job of the previous super-batch
-    inflight = None           # (ids, export result) launched on the GPU, not yet fetched
+    inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
+    copy_stream = torch.cuda.Stream(dev)
 
     def launch(group):
         nonlocal total
@@ -111,13 +112,28 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         ex = model.engine.export_reads(out["signal"], torch.from_numpy(read_first).to(dev), profile_dict["digitisation"],
                                        profile_dict["range"], profile_dict["offset_mean"], rna=rna, want_pa=False,
                                        want_dac=True)
-        return [n for _, n in group], ex
+        # D2H on its own stream, so that it runs beside the next super-batch's kernels instead of queueing behind them.
+        # The whole capacity is copied (its size is known without a sync; 16 MB per 32 k chunks) into pinned memory.
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            offs_h = torch.empty(ex["offsets"].shape, dtype=torch.int64, pin_memory=True)
+            dac_h = torch.empty(ex["dac"].shape, dtype=torch.int16, pin_memory=True)
+            offs_h.copy_(ex["offsets"], non_blocking=True)
+            dac_h.copy_(ex["dac"], non_blocking=True)
+            ex["offsets"].record_stream(copy_stream)
+            ex["dac"].record_stream(copy_stream)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        return [n for _, n in group], offs_h, dac_h, done
 
     def collect(job):
         nonlocal pending
-        ids, ex = job
-        offs = ex["offsets"].cpu().numpy()
-        dac = ex["dac"][: int(offs[-1])].cpu().numpy()
+        ids, offs_h, dac_h, done = job
+        done.synchronize()
+        offs = offs_h.numpy()
+        dac = dac_h.numpy()[: int(offs[-1])]
         recs = writer.dac_records(ids, dac, offs)
         if pending is not None:
             pending.result()
