@@ -90,6 +90,7 @@ class BLOW5Writer:
         self.n_written = 0
         self.binary = self.filename.endswith(".blow5")
         self.compress_level = 1               # zlib level of BLOW5 records; any level is a valid zlib stream
+        self._pool = None
 
     # ------------------------------------------------------------------ header
     def header_attributes(self) -> dict:
@@ -210,10 +211,11 @@ class BLOW5Writer:
                 f.write(struct.pack("<I", len(hdr)) + hdr)
             # zlib releases the GIL: compress records on worker threads, write in order
             # (the reference: write_record_batch(threads=cpu_count), signal_io.py:167-171)
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
-                for blob in pool.map(self._blow5_record, recs):
-                    f.write(blob)
+            if self._pool is None:                     # kept for the writer's lifetime: one save per super-batch
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1))
+            for blob in self._pool.map(self._blow5_record, recs):
+                f.write(blob)
             f.write(self._EOF)
 
 
