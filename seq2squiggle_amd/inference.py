@@ -194,13 +194,26 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     if saved_weights is None:
         raise FileNotFoundError("no model weights given: downloading released weights needs network access; pass "
                                 "--model <file.ckpt>")
-    reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
     first_chunk = 0
-    if world > 1:                      # every rank derives the same read list, then keeps its contiguous share
-        reads = list(reads)
-        lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
-        reads = reads[lo:hi]
-        logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
+    if world > 1 and not read_input:
+        # every rank replays the sampler for the read lengths, then builds only its own contiguous share of the reads
+        from .utils import preprocess_genome, sample_read_shard
+        genome_seqs, genome_lens = preprocess_genome(fasta)
+        picked = {}
+
+        def shard_of(lens):
+            lo, hi, picked["first"] = shard_reads(lens, config["seq_kmer"], world)[rank]
+            return lo, hi
+        reads, lens = sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of)
+        first_chunk = picked["first"]
+        logger.info(f"rank {rank}/{world}: {len(reads)} of {len(lens)} reads, first global chunk {first_chunk}")
+    else:
+        reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
+        if world > 1:                  # read mode: every rank parses the same file, then keeps its contiguous share
+            reads = list(reads)
+            lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
+            reads = reads[lo:hi]
+            logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
 
     load_model = seq2squiggle.load_from_checkpoint(
         checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean, dwell_std=dwell_std, noise_std=noise_std,

@@ -191,11 +191,16 @@ def reverse_complement(f):
     return f.translate(_COMPLEMENT)[::-1]
 
 
-def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20):
+def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20,
+             materialise=None):
     """Sample reads from the reference (utils.py:415-479).  The order of draws from the global `random`
     stream (start position, strand, N replacement) and the per-(read, retry) scipy seed
     `seed + read_i * (max_retries + 1) + retries` are those of the reference, so a seed selects the same
-    read set."""
+    read set.
+
+    materialise = (lo, hi): only the accepted reads lo..hi-1 are built as strings, the others are returned as their
+    LENGTH (an int) -- every draw is still made, so the stream and the read set are unchanged; a rank of a sharded run
+    pays the string work (slice copy, reverse complement) only for its own reads."""
     sampled_reads = []
     total_genome_len = sum(genome_lens)
     # the first-try lengths of a block of reads in one vectorised pass (the per-seed scipy call costs ~100 us and is what
@@ -224,7 +229,10 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
                 read_strand = "+"
             if read_check(read, read_length, read_i, profile, min_read_len):
                 if "N" in read:
-                    read = N_to_ACTG(read)
+                    read = N_to_ACTG(read)                 # (draws from `random`: never skipped)
+                if materialise is not None and not (materialise[0] <= len(sampled_reads) < materialise[1]):
+                    sampled_reads.append(len(read))
+                    break
                 if read_strand == "-":
                     read = reverse_complement(read)
                 sampled_reads.append(read)
@@ -248,15 +256,35 @@ def export_fasta(read_l, fasta):
     return out_file
 
 
-def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta, seed, save=False, distr="expon",
-                                profile="dna-r10-min", min_read_len=30):
-    """utils.py:495-582 (same argument checks and messages)."""
+def _check_sampling_args(n, r, c):
+    """utils.py:528-541."""
     if n <= 0 and c <= 0:
         raise ValueError("You need to specify the coverage c or the number of reads n")
     if n != -1 and c != -1:
         raise ValueError("You can only either specify the coverage c or the number of reads, but not both")
     if r <= 0:
         raise ValueError("You need to specify the read length r")
+
+
+def sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of):
+    """One rank's share of the read set sample_reads_from_reference would draw: pass 1 replays the sampler for the read
+    LENGTHS only, `shard_of(lengths)` -> (lo, hi) picks the rank's contiguous range, pass 2 replays it from the same
+    `random` state and builds the strings of that range.  -> (reads lo..hi-1 as (seq, uuid) pairs, all read lengths)."""
+    _check_sampling_args(n, r, c)
+    total_len = sum(len(seq) for seq in genome_seqs)
+    seq_num = n if n != -1 else round(c * total_len / r)
+    state = random.getstate()
+    lens = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(0, 0))
+    lo, hi = shard_of(lens)
+    random.setstate(state)
+    reads = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(lo, hi))
+    return [(rd, str(uuid4())) for rd in reads[lo:hi]], lens
+
+
+def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta, seed, save=False, distr="expon",
+                                profile="dna-r10-min", min_read_len=30):
+    """utils.py:495-582 (same argument checks and messages)."""
+    _check_sampling_args(n, r, c)
     total_len = sum(len(seq) for seq in genome_seqs)
     avg_genome_len = total_len / len(genome_seqs)
     seq_num = n if n != -1 else round(c * total_len / r)

@@ -98,3 +98,30 @@ def test_profiles_match_reference_table():
         U.update_config("dna-r7", {})
     p = U.update_profile(U.get_profile("dna-r10-prom"), sample_rate=4000, bps=None)
     assert p["sample_rate"] == 4000 and p["bps"] == 400
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_sampling_equals_slices_of_the_full_read_set(world):
+    """sample_read_shard (lengths-only replay + strings for one range) gives every rank exactly its slice of the read set
+    the unsharded sampler draws for the same seed, including reads with N (extra `random` draws) and rejected tries."""
+    from seq2squiggle_amd.parallel import shard_reads
+    rng = np.random.default_rng(3)
+    contig2 = "".join(rng.choice(list("ACGTN"), 20000, p=[.24, .24, .24, .24, .04]))
+    seqs, lens = zip(*[U.process_genome(s) for s in (next(iter(U.read_fasta(LAMBDA)))[0][:30000], contig2)])
+    args = (list(seqs), list(lens), 60, 3000, -1)
+    random.seed(5)
+    full, _ = U.sample_reads_from_reference(*args, {"max_dna_len": 16}, "x.fa", 5, False, "expon", "dna-r10-min", 30)
+    full = [s for s, _ in full]
+    got = []
+    for rank in range(world):
+        random.seed(5)
+        box = {}
+
+        def shard_of(ls, rank=rank):
+            lo, hi, box["first"] = shard_reads(ls, 9, world)[rank]
+            return lo, hi
+        reads, ls = U.sample_read_shard(*args, 5, "expon", "dna-r10-min", 30, shard_of)
+        assert ls == [len(s) for s in full]
+        assert box["first"] == sum(-(-(max(L - 8, 0)) // 16) for L in ls[: len(got)])
+        got += [s for s, _ in reads]
+    assert got == full and any("N" in s for s in seqs)
