@@ -126,25 +126,33 @@ def draw_expon_dis(mean, seed, total_len):
 
 def _mt19937_first_double(seeds: np.ndarray) -> np.ndarray:
     """random_sample() of np.random.RandomState(seed) for a whole vector of integer seeds at once: init_genrand, the
-    twist of state words 0 and 1 (which only needs words 0-2, 397, 398) and the 53-bit double of the legacy generator."""
-    mt = np.empty((399, seeds.shape[0]), dtype=np.uint64)
-    mt[0] = seeds.astype(np.uint64) & 0xFFFFFFFF
+    twist of state words 0 and 1 (which only needs words 0-2, 397, 398) and the 53-bit double of the legacy generator.
+    uint32 arrays wrap modulo 2^32 like the C code; the recurrence runs in place on one L1-sized vector."""
+    x = (np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    t = np.empty_like(x)
+    keep = {0: x.copy()}
+    mul = np.uint32(1812433253)
     for i in range(1, 399):
-        prev = mt[i - 1]
-        mt[i] = (1812433253 * (prev ^ (prev >> 30)) + i) & 0xFFFFFFFF
+        np.right_shift(x, 30, out=t)
+        t ^= x
+        t *= mul
+        t += np.uint32(i)
+        x, t = t, x
+        if i in (1, 2, 397, 398):
+            keep[i] = x.copy()
 
     def twist(a, b, c):
-        y = (a & 0x80000000) | (b & 0x7FFFFFFF)
-        return c ^ (y >> 1) ^ np.where(y & 1, 0x9908B0DF, 0).astype(np.uint64)
+        y = (a & np.uint32(0x80000000)) | (b & np.uint32(0x7FFFFFFF))
+        return c ^ (y >> 1) ^ np.where(y & np.uint32(1), np.uint32(0x9908B0DF), np.uint32(0))
 
     def temper(y):
         y = y ^ (y >> 11)
-        y = y ^ ((y << 7) & 0x9D2C5680)
-        y = y ^ ((y << 15) & 0xEFC60000)
-        return (y ^ (y >> 18)) & 0xFFFFFFFF
+        y = y ^ ((y << 7) & np.uint32(0x9D2C5680))
+        y = y ^ ((y << 15) & np.uint32(0xEFC60000))
+        return y ^ (y >> 18)
 
-    a = temper(twist(mt[0], mt[1], mt[397])) >> 5
-    b = temper(twist(mt[1], mt[2], mt[398])) >> 6
+    a = temper(twist(keep[0], keep[1], keep[397])) >> 5
+    b = temper(twist(keep[1], keep[2], keep[398])) >> 6
     return (a.astype(np.float64) * 67108864.0 + b.astype(np.float64)) / 9007199254740992.0
 
 
@@ -206,20 +214,26 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
     # the first-try lengths of a block of reads in one vectorised pass (the per-seed scipy call costs ~100 us and is what
     # the reference's sampler spends its time in); retries and the other distributions go through scipy one by one
     fast = distr == "expon" and r > 0 and 0 <= seed and seed + num_seqs * (max_retries + 1) < 2 ** 32
-    block, block_lo = None, 0
+    blocks = {}                        # retry level -> (first read of the block, lengths); level 0 in blocks of 8192 reads
+
+    def fast_length(read_i, level):
+        lo, vals = blocks.get(level, (0, ()))
+        if not (lo <= read_i < lo + len(vals)):
+            lo = read_i
+            idx = np.arange(read_i, min(num_seqs, read_i + (8192 if level == 0 else 2048)), dtype=np.int64)
+            vals = draw_expon_dis_many(r, seed + idx * (max_retries + 1) + level, total_len)
+            blocks[level] = (lo, vals)
+        return int(vals[read_i - lo])
+
     for read_i in range(num_seqs):
-        if fast and (block is None or read_i >= block_lo + len(block)):
-            block_lo = read_i
-            idx = np.arange(read_i, min(num_seqs, read_i + 8192), dtype=np.int64)
-            block = draw_expon_dis_many(r, seed + idx * (max_retries + 1), total_len)
         retries = 0
         while retries < max_retries:
             start_pos = random.randint(0, total_genome_len - 1)
             genome_index, start_index = get_genome_and_position(genome_lens, start_pos)
             genome = genome_seqs[genome_index]
             unique_seed = seed + read_i * (max_retries + 1) + retries
-            if fast and retries == 0:
-                read_length = int(block[read_i - block_lo])
+            if fast:
+                read_length = fast_length(read_i, retries)
             else:
                 read_length = int(_DISTR[distr](r, unique_seed, total_len)) if r > 0 else len(genome)
             read = genome[start_index:start_index + read_length]
