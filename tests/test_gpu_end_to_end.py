@@ -187,3 +187,25 @@ def test_cli_pod5_output_equals_blow5_output(tmp_path):
         assert p["read_id"] == uuid.uuid5(uuid.NAMESPACE_DNS, b["read_id"])
         assert np.array_equal(p["signal"], b["signal"])
         assert abs(p["calibration_scale"] - b["range"] / b["digitisation"]) < 1e-6
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object and (at N=1) the CPU baseline."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--reads", "60"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["unit"] == "samples/s" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["avg_launch_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["parity"]["dwell_indices_equal"] and cb["parity"]["signal_mae_pa"] < cb["parity"]["tolerance_mae_pa"]
