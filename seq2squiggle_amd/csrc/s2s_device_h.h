@@ -30,6 +30,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define S2S_ALWAYS_RESCALE 0
 #endif
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
+// Scheduling barriers pin the weight-unit / K,V-fragment loads in front of the MFMAs they are prefetched behind; the
+// -DS2S_NO_SB_* builds measure what they are worth (the one in the attention pass: 15 % of the kernel).
 #ifndef S2S_NO_SB_ATT
 #define SB_ATT() __builtin_amdgcn_sched_barrier(0)
 #else
