@@ -191,25 +191,6 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
             va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         }
         SB_ATT();
-#ifdef S2S_EXP_SGB
-        if (h2 > 0 && !SAFE && NQ == 2 && HK == 4) {
-#if S2S_EXP_SGB == 1
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                 // QK^T
-            __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);                // exp + split of the first k-block
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#else
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                 // QK^T of tile 0
-#pragma unroll
-            for (int i = 0; i < 20; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-#endif
         }
 #endif
         // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
