@@ -191,8 +191,6 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
             va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         }
         SB_ATT();
-        }
-#endif
         // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
         // beside the other's exponentials inside the same wave
         f32x4 s[NQ][HK];
