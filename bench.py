@@ -66,23 +66,27 @@ def end_to_end(mode):
     from seq2squiggle_amd.inference import inference_run
     from seq2squiggle_amd.utils import set_seeds
     fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "o.blow5")
-        set_seeds(42)
-        t0 = time.perf_counter()
-        m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
-                          fasta=fasta, read_input=False, n=1000, r=5000, c=-1, out=out, profile="dna-r10-prom", dwell_mean=None,
-                          dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True, distr="expon",
-                          predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None, bps=None,
-                          digitisation=None, range_val=None, offset_mean=None, offset_std=None, median_before_mean=None,
-                          median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30, preserve_read_ids=False,
-                          seed=42, mode=mode)
-        el = time.perf_counter() - t0
-        size = os.path.getsize(out)
-        chunks = m.chunks_done
-        m.engine.close()
+    runs = []
+    for _ in range(2):                 # the first call also pays the process's one-time costs (pinned buffers, thread pool)
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "o.blow5")
+            set_seeds(42)
+            t0 = time.perf_counter()
+            m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
+                              fasta=fasta, read_input=False, n=1000, r=5000, c=-1, out=out, profile="dna-r10-prom",
+                              dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
+                              distr="expon", predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None,
+                              bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
+                              median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
+                              preserve_read_ids=False, seed=42, mode=mode)
+            runs.append(time.perf_counter() - t0)
+            size = os.path.getsize(out)
+            chunks = m.chunks_done
+            m.engine.close()
+    el = runs[1]
     return {"workload": "example lambda genome -n 1000 -r 5000 -> .blow5 (zlib records), seed 42", "seconds": el,
-            "reads_per_sec": 1000 / el, "chunks": chunks, "chunks_per_sec": chunks / el, "output_bytes": size,
+            "first_call_seconds": runs[0], "reads_per_sec": 1000 / el, "chunks": chunks, "chunks_per_sec": chunks / el,
+            "output_bytes": size,
             "includes": "engine creation, read sampling, chunking, kernels, export, D2H, compression, file write"}
 
 
