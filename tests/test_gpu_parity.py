@@ -372,3 +372,44 @@ def test_edge_inputs_and_parameters(mode, over):
     d = np.abs(y - r)
     assert d.mean() < MAE_TOL and d.max() < 5e-3, (d.mean(), d.max())
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("enc_l,dec_l,pre_l", [(1, 3, 0), (3, 1, 2), (4, 4, 4)])
+def test_other_layer_counts(mode, enc_l, dec_l, pre_l):
+    """The C ABI takes 1..4 encoder/decoder layers and 0..4 pre-net layers (s2s_config): checkpoints of those shapes, built
+    from perturbed copies of the synthetic k=9 layers, against the oracle (injected variates, both samplers on)."""
+    sd0, cfg0 = load_ckpt("k9")
+    cfg = dict(cfg0, encoder_layers=enc_l, decoder_layers=dec_l, pre_layers=pre_l)
+    gen = torch.Generator().manual_seed(100 * enc_l + 10 * dec_l + pre_l)
+    sd = {k: v.clone() for k, v in sd0.items() if ".layer_stack" not in k and "pre_net_stack" not in k}
+
+    def perturbed(t):
+        return t * (1.0 + 0.05 * torch.randn(t.shape, generator=gen)) + 0.01 * torch.randn(t.shape, generator=gen)
+    for stack, n_src, n_dst in (("encoders.layer_stack", cfg0["encoder_layers"], enc_l),
+                                ("decoders.layer_stack_FFT", cfg0["decoder_layers"], dec_l)):
+        for l in range(n_dst):
+            src = f"{stack}.{l % n_src}."
+            for k, v in sd0.items():
+                if k.startswith(src):
+                    sd[f"{stack}.{l}." + k[len(src):]] = v.clone() if l < n_src else perturbed(v)
+    for i in range(pre_l):
+        for part in ("weight", "bias"):
+            v = sd0[f"encoders.pre_net_stack.0.{part}"]
+            sd[f"encoders.pre_net_stack.{i}.{part}"] = v.clone() if i == 0 else perturbed(v)
+    eng = S.Engine(sd, cfg, mode=mode)
+    rng = np.random.default_rng(enc_l + dec_l)
+    reads = ["".join(rng.choice(list("ACGT"), 700)) for _ in range(2)]
+    codes = np.concatenate([O.encode_read(r, 9) for r in reads])
+    bases, nv = chunker.codes_to_bases(codes)
+    B = codes.shape[0]
+    g = torch.rand(B, 16, generator=gen) * 25
+    z = torch.randn(B, 250, generator=gen)
+    ref = O.predict_chunks(sd, cfg, codes, O.PredictParams(**P()), inject_g=g, inject_z01=z)
+    out = eng.predict_chunks(torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), S.PredictParams(**P()),
+                             inject_g=g.cuda(), inject_z01=z.cuda())
+    y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
+    assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
+    assert np.array_equal(y == 0, r == 0)
+    assert np.abs(y - r).mean() < MAE_TOL * max(1, dec_l / 2) and np.abs(y - r).max() < MAX_TOL * max(1, dec_l / 2)
+    eng.close()
