@@ -209,3 +209,30 @@ def test_bench_contract_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["parity"]["dwell_indices_equal"] and cb["parity"]["signal_mae_pa"] < cb["parity"]["tolerance_mae_pa"]
+
+
+def test_rna_profile_streaming_equals_reference_flow(tmp_path):
+    """rna-004: dwell 4000/130 = 30.8 samples per base (16 k-mers overflow the 250-sample chunk: crop path), signals
+    reversed per read (signal_io.py:140-141) -- on the GPU in the streaming path, on the host in the reference flow."""
+    from seq2squiggle_amd.cli import set_config
+    rng = np.random.default_rng(2)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for i, n in enumerate([30, 100, 700]):
+            f.write(f">t{i}\n{''.join(rng.choice(list('ACGU'), n))}\n")
+    outs = []
+    for streaming in (True, False):
+        out = tmp_path / f"r{int(streaming)}.blow5"
+        inference_run(config=set_config(None), saved_weights=os.path.join(GOLDEN, "synthetic_k9.ckpt"), fasta=str(fa),
+                      read_input=True, n=-1, r=1000, c=-1, out=str(out), profile="rna-004-prom", dwell_mean=None, dwell_std=0.0,
+                      noise_std=0.0, noise_sampling=False, duration_sampling=False, distr="expon", predict_batch_size=16,
+                      export_every_n_samples=20, sample_rate=None, bps=None, digitisation=None, range_val=None,
+                      offset_mean=None, offset_std=None, median_before_mean=None, median_before_std=None, min_noise=0.0,
+                      min_duration=3, min_read_len=30, preserve_read_ids=True, seed=3, streaming=streaming)
+        outs.append(signal_io.read_blow5(str(out)))
+    (ha, a), (hb, b) = outs
+    assert "rna" in ha and [r["read_id"] for r in a] == [r["read_id"] for r in b] == ["t0", "t1", "t2"]
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["signal"], rb["signal"]) and len(ra["signal"]) > 0
+    # every chunk is full (16 x 31 > 250): 250 samples per chunk minus ReLU zeros
+    assert len(a[2]["signal"]) > 0.9 * 250 * -(-(700 - 8) // 16)
