@@ -236,3 +236,27 @@ def test_rna_profile_streaming_equals_reference_flow(tmp_path):
         assert np.array_equal(ra["signal"], rb["signal"]) and len(ra["signal"]) > 0
     # every chunk is full (16 x 31 > 250): 250 samples per chunk minus ReLU zeros
     assert len(a[2]["signal"]) > 0.9 * 250 * -(-(700 - 8) // 16)
+
+
+def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
+    """SURVEY 8e on the real device path: RANK/WORLD_SIZE = r/3 runs (one after the other, all on GPU 0) write
+    out.rank{r}.blow5; their reads, concatenated in rank order, carry exactly the samples of the single-process run
+    (same read set from the seed, RNG keyed by the global chunk index)."""
+    lam = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+    base = [sys.executable, "-m", "seq2squiggle_amd", "predict", lam, "-n", "30", "-r", "2000", "-m",
+            os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--seed", "9"]
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(base + ["-o", str(tmp_path / "one.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env0)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, one = signal_io.read_blow5(str(tmp_path / "one.blow5"))
+    parts = []
+    for rank in range(3):
+        env = dict(env0, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0")
+        r = subprocess.run(base + ["-o", str(tmp_path / "out.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        _, recs = signal_io.read_blow5(str(tmp_path / f"out.rank{rank}.blow5"))
+        assert len(recs) > 0
+        parts += recs
+    assert len(parts) == len(one) == 30
+    for a, b in zip(parts, one):
+        assert np.array_equal(a["signal"], b["signal"])
