@@ -11,7 +11,9 @@
  *   - all launches are stream-ordered on `stream` (a hipStream_t passed as void*, NULL = default
  *     stream) and asynchronous w.r.t. the host;
  *   - return value 0 = success, negative = error; s2s_last_error() gives the message;
- *   - a handle may be used from one host thread at a time; there is no global state.
+ *   - a handle may be used from one host thread and on one stream at a time (it owns a one-tile workspace that
+ *     consecutive launches reuse in stream order); every call makes the handle's device current for its duration
+ *     and restores the caller's; there is no global state.
  */
 #ifndef S2S_HIP_H
 #define S2S_HIP_H

@@ -483,6 +483,18 @@ int fail(s2s_handle* h, int code, const std::string& msg) {
             return fail((h), S2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Makes the handle's device current for the duration of a call and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 size_t layer_floats() { return 4 * (64 * 64 + 64) + 2 * 64 + (256 * 64 + 256) + (64 * 256 + 64) + 2 * 64; }
 size_t mlp_floats() { return 64 * 64 + 64 + 64 + 1; }
 
@@ -711,7 +723,8 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     int ndev = 0;
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(nullptr, S2S_ERR_ARG, "no such HIP device");
-    HIP_TRY(nullptr, hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(nullptr, S2S_ERR_HIP, "hipSetDevice failed");
     hipDeviceProp_t prop;
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -785,7 +798,7 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
 
 void s2s_destroy(s2s_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     for (auto& ev : h->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->ws_enc) (void)hipFree(h->ws_enc);
@@ -805,6 +818,8 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
     if (B < 0) return fail(h, S2S_ERR_ARG, "B < 0");
     if (B == 0) return S2S_OK;
     if (!bases || !n_valid || !params || !out_signal || !out_dur) return fail(h, S2S_ERR_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, S2S_ERR_HIP, "hipSetDevice failed");
     if (!(params->min_duration >= 0.0f)) return fail(h, S2S_ERR_ARG, "min_duration must be >= 0");
     if (!params->duration_sampling && !(params->dwell_std > 0.0f) && !(params->dwell_mean >= 0.0f))
         return fail(h, S2S_ERR_ARG, "dwell_mean must be >= 0");
@@ -880,6 +895,8 @@ int s2s_export_reads(s2s_handle* h, void* stream_, const float* signal, int32_t 
     if (!h) return S2S_ERR_ARG;
     if (B < 0 || R < 0) return fail(h, S2S_ERR_ARG, "negative size");
     if (!signal || !read_first || !out_offsets) return fail(h, S2S_ERR_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, S2S_ERR_HIP, "hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (B + 1 > h->ws_export_cap) {          // grows outside of the steady state only
         HIP_TRY(h, hipStreamSynchronize(stream));
@@ -908,6 +925,8 @@ int s2s_philox_u32(s2s_handle* h, void* stream_, uint64_t seed, uint32_t c0, uin
     if (!h) return S2S_ERR_ARG;
     if (n < 0 || !out) return fail(h, S2S_ERR_ARG, "bad argument");
     if (n == 0) return S2S_OK;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, S2S_ERR_HIP, "hipSetDevice failed");
     hipLaunchKernelGGL(s2s_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        (unsigned)seed, (unsigned)(seed >> 32), c0, c1, c2, c3, n, out);
     HIP_TRY(h, hipGetLastError());
