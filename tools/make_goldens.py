@@ -21,7 +21,7 @@ import torch
 import yaml
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("S2S_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 # ----------------------------------------------------------------------------- stubs
