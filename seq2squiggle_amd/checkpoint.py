@@ -53,7 +53,7 @@ def state_dict_to_blob(sd: Dict[str, torch.Tensor], cfg: dict) -> np.ndarray:
     return np.concatenate([sd[n].detach().float().cpu().numpy().ravel() for n in blob_names(cfg)]).astype(np.float32)
 
 
-MODES = {"f32": 0, "f16x3": 1, "f16x3w": 2}
+MODES = {"f32": 0, "f16x3": 1, "f16x3w": 2, "f16": 3}     # f16: reduced precision (see include/s2s_hip.h)
 
 
 def config_to_c(cfg: dict, mode: str = "f16x3") -> S2SConfig:

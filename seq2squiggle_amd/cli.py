@@ -79,7 +79,7 @@ def version():
 @click.option("-m", "--model", type=click.Path(exists=False, dir_okay=False), help="Model weights (.ckpt).")
 @click.option("-y", "--config", help="YAML configuration file overriding the defaults.")
 @click.option("-v", "--verbosity", type=click.Choice(["debug", "info", "warning", "error"], case_sensitive=False), default="info")
-@click.option("--compute-mode", default="f16x3", type=click.Choice(["f16x3", "f32"]), hidden=True,
+@click.option("--compute-mode", default="f16x3", type=click.Choice(["f16x3", "f32", "f16"]), hidden=True,
               help="Decoder arithmetic of the MI355X engine.")
 @click.pass_context
 def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profile, show_advanced_options, noise_sampler,

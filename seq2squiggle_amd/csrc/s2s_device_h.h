@@ -56,9 +56,13 @@ __device__ __forceinline__ h8 as_h8(const f32x4 v) { return __builtin_bit_cast(h
 // and the mix form is lost), the empty asm makes the packed hi opaque so its halves are reused through
 // op_sel instead of being converted again, and the file is built with -fno-slp-vectorize (the SLP
 // vectoriser would turn the two fmas into v_pk_fma_f32 plus separate conversions: five instructions).
+// LO = false (the reduced-precision S2S_MODE_F16 decoder): only the f16 rounding of x is kept, lo = 0 -- one
+// v_cvt_pk_f16_f32 per pair; every MFMA that would take a lo operand is skipped at compile time by its caller.
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+template <bool LO = true>
 __device__ __forceinline__ void split2(const float a, const float b, const float one, unsigned& hi, unsigned& lo) {
     unsigned hb = __builtin_bit_cast(unsigned, (h2v{(_Float16)a, (_Float16)b}));
+    if (!LO) { hi = hb; lo = 0u; return; }
     asm("" : "+v"(hb));
     const h2v h = __builtin_bit_cast(h2v, hb);
     const h2v l = {(_Float16)__builtin_fmaf(a, one, -(float)h[0]), (_Float16)__builtin_fmaf(b, one, -(float)h[1])};
@@ -67,6 +71,7 @@ __device__ __forceinline__ void split2(const float a, const float b, const float
 }
 // p = exp2(s) for four scores, split.  p itself is not needed afterwards (the row sum comes out of
 // the MFMA with a ones operand).
+template <bool LO = true>
 __device__ __forceinline__ void exp_split4(const f32x4 s, const float one, unsigned& h0, unsigned& h1, unsigned& l0,
                                            unsigned& l1) {
     const float e0 = (S2S_ABL & 1) ? s[0] : __builtin_amdgcn_exp2f(s[0]), e1 = (S2S_ABL & 1) ? s[1] : __builtin_amdgcn_exp2f(s[1]);
@@ -75,26 +80,28 @@ __device__ __forceinline__ void exp_split4(const f32x4 s, const float one, unsig
         h0 = __float_as_uint(e0); l0 = __float_as_uint(e1); h1 = __float_as_uint(e2); l1 = __float_as_uint(e3);
         return;
     }
-    split2(e0, e1, one, h0, l0);
-    split2(e2, e3, one, h1, l1);
+    split2<LO>(e0, e1, one, h0, l0);
+    split2<LO>(e2, e3, one, h1, l1);
 }
 typedef unsigned uv4 __attribute__((ext_vector_type(4)));
 typedef unsigned uv2 __attribute__((ext_vector_type(2)));
+template <bool LO = true>
 __device__ __forceinline__ HL split8(const f32x4 t0, const f32x4 t1, const float one) {
     unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2(t0[0], t0[1], one, h0, l0);
-    split2(t0[2], t0[3], one, h1, l1);
-    split2(t1[0], t1[1], one, h2, l2);
-    split2(t1[2], t1[3], one, h3, l3);
+    split2<LO>(t0[0], t0[1], one, h0, l0);
+    split2<LO>(t0[2], t0[3], one, h1, l1);
+    split2<LO>(t1[0], t1[1], one, h2, l2);
+    split2<LO>(t1[2], t1[3], one, h3, l3);
     HL o;
     o.hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2, h3}));
     o.lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
     return o;
 }
+template <bool LO = true>
 __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h4& lo) {
     unsigned h0, h1, l0, l1;
-    split2(t[0], t[1], one, h0, l0);
-    split2(t[2], t[3], one, h1, l1);
+    split2<LO>(t[0], t[1], one, h0, l0);
+    split2<LO>(t[2], t[3], one, h1, l1);
     hi = __builtin_bit_cast(h4, (uv2{h0, h1}));
     lo = __builtin_bit_cast(h4, (uv2{l0, l1}));
 }
@@ -112,34 +119,38 @@ template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
 
 // acc[q] += W_unit * x[q]: one 16-row m-tile, K = 64 as two k-blocks, three products each.
 // Unit layout (4 KiB): [kb0 hi][kb0 lo][kb1 hi][kb1 lo], 16 B per lane each.
-template <int NQ>
+template <int NQ, bool LO = true>
 __device__ __forceinline__ void mm_unit_h(f32x4 (&acc)[NQ], const f32x4 (&f)[4], const HL (&x)[NQ][2]) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const h8 wh = as_h8(f[2 * kb]), wl = as_h8(f[2 * kb + 1]);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wh, x[q][kb].hi, acc[q]);
+        if (LO) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wh, x[q][kb].lo, acc[q]);
+            for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wh, x[q][kb].lo, acc[q]);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wl, x[q][kb].hi, acc[q]);
+            for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(wl, x[q][kb].hi, acc[q]);
+        }
     }
 }
 
 // acc[q] += (W_unit * x[q])^T: the A and B fragments of the K = 32 MFMA have the same lane layout, so swapping the operands
 // transposes the product for free -- rows of the accumulator tile are then 4 consecutive TIME columns, its column one
 // output feature (used for V^T, whose LDS rows run along the keys).
-template <int NQ>
+template <int NQ, bool LO = true>
 __device__ __forceinline__ void mm_unit_h_t(f32x4 (&acc)[NQ], const f32x4 (&f)[4], const HL (&x)[NQ][2]) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const h8 wh = as_h8(f[2 * kb]), wl = as_h8(f[2 * kb + 1]);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].hi, wh, acc[q]);
+        if (LO) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].lo, wh, acc[q]);
+            for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].lo, wh, acc[q]);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].hi, wl, acc[q]);
+            for (int q = 0; q < NQ; ++q) acc[q] = MFMAH(x[q][kb].hi, wl, acc[q]);
+        }
     }
 }
 
@@ -164,7 +175,7 @@ __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const f
 //     shift-invariant, so this is exact as long as no later score beats m by the f16 range of P_hi; if one does, the
 //     row sum turns inf/NaN, which the caller checks once per head, and then runs
 //   SAFE = true (rare): a textbook online softmax, the running max raised and the sums rescaled in every pass.
-template <int NQ, int NKT, int TV, bool SAFE>
+template <int NQ, int NKT, int TV, bool SAFE, bool LO = true>
 __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, const _Float16* __restrict__ vp, const h8 (&qb)[NQ],
                                            const h8 ones, const float one, const int g, f32x4 (&oH)[NQ], f32x4 (&oL)[NQ],
                                            f32x4 (&lH)[NQ], f32x4 (&lL)[NQ]) {
@@ -232,7 +243,8 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
                 } else {                              // safe attempt: raise the running max, rescale the sums
                     const float delta = fmaxf(mh, 0.0f);
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
-                    oH[q] *= alpha; oL[q] *= alpha; lH[q] *= alpha; lL[q] *= alpha;
+                    oH[q] *= alpha; lH[q] *= alpha;
+                    if (LO) { oL[q] *= alpha; lL[q] *= alpha; }
                     m[q] += delta;
                     negm[q] = f32x4{-m[q], -m[q], -m[q], -m[q]};
 #pragma unroll
@@ -246,8 +258,8 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
 #pragma unroll
             for (int kb = 0; kb < HB; ++kb) {
                 unsigned h0, h1, h2_ = 0, h3 = 0, l0, l1, l2 = 0, l3 = 0;
-                exp_split4(s[q][2 * kb], one, h0, h1, l0, l1);
-                if (2 * kb + 1 < HK) exp_split4(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
+                exp_split4<LO>(s[q][2 * kb], one, h0, h1, l0, l1);
+                if (2 * kb + 1 < HK) exp_split4<LO>(s[q][2 * kb + 1], one, h2_, h3, l2, l3);
                 P[q][kb].hi = __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3}));
                 P[q][kb].lo = __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3}));
             }
@@ -255,10 +267,10 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
             for (int kb = 0; kb < HB; ++kb) {
                 if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
                 oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                if (LO) oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
                 if (!(S2S_ABL & 64)) {
                 lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
-                lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
+                if (LO) lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
                 }
             }
         }
@@ -266,7 +278,7 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
 }
 
 // One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
-template <int NQ, int WAVES, int NKT, int TV>
+template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr) {
@@ -283,7 +295,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 
     HL xb[NQ][2];                                     // block input as B operands
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
+    for (int q = 0; q < NQ; ++q) { xb[q][0] = split8<LO>(X[q][0], X[q][1], one); xb[q][1] = split8<LO>(X[q][2], X[q][3], one); }
 
     if (!(S2S_ABL & 4)) __syncthreads();              // every wave is done reading the previous block's K/V
     DIAG_STAMP(0);
@@ -300,22 +312,22 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         f32x4 ak[NQ], av[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
-        mm_unit_h<NQ>(ak, fa, xb);
+        mm_unit_h<NQ, LO>(ak, fa, xb);
         SB_GEMM();
         if (!(S2S_ABL & 4096) || p == 3) load_unit(fa, ws);
         WS_ADVP(1024, 2048);                                   // Wk, pair p+1 (after the last pair: Wq, pair 0)
         SB_GEMM();
-        mm_unit_h_t<NQ>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
+        mm_unit_h_t<NQ, LO>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
         const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // K accumulator rows 4g..4g+3 = head, d0..d0+3
         const int vrow = (2 * p + (c >> 3)) * 16 + (c & 7);    // V^T row of this lane's feature (hi; lo is 8 rows below)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int key = 16 * (qt0 + q) + c;
             h4 hi, lo;
-            split4(ak[q] + bk, one, hi, lo);
+            split4<LO>(ak[q] + bk, one, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
-            split4(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
+            split4<LO>(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
             *reinterpret_cast<h4*>(Vl + vrow * G::VS + 16 * (qt0 + q) + 4 * g) = hi;
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + 16 * (qt0 + q) + 4 * g) = lo;
         }
@@ -349,14 +361,14 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 qa[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) qa[q] = f32x4{0, 0, 0, 0};
-            if (pp == 0) mm_unit_h<NQ>(qa, fa, xb); else mm_unit_h<NQ>(qa, fb, xb);
+            if (pp == 0) mm_unit_h<NQ, LO>(qa, fa, xb); else mm_unit_h<NQ, LO>(qa, fb, xb);
             SB_GEMM();
             // Q^T rows live 4 per lane group; the S MFMA wants all 8 d of a head in every lane
             // ([Q_hi | Q_lo | Q_hi | Q_lo] over the lane groups): re-layout through the wave's scratch
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 h4 hi, lo;
-                split4((qa[q] + bq) * c1, one, hi, lo);               // scores come out in log2 units
+                split4<LO>((qa[q] + bq) * c1, one, hi, lo);               // scores come out in log2 units
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 0) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = hi;
                 *reinterpret_cast<h4*>(Ql + (((q * 2 + 1) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
@@ -373,23 +385,23 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
-                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
 #if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)   // (NO_FALLBACK: test-only build, proves test_peaked_attention... needs the redo)
                 {
                     bool bad = false;                          // inf or NaN row sum: some P_hi left the f16 range
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + lL[q][0] <= 3.0e38f);
+                    for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + (LO ? lL[q][0] : 0.0f) <= 3.0e38f);
                     const bool redo = __any(bad);
 #ifdef S2S_DIAG
                     if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
 #endif
-                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
                 }
 #endif
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const f32x4 t = oH[q] + oL[q];
-                    const float inv = 1.0f / (lH[q][0] + lL[q][0]);
+                    const f32x4 t = LO ? oH[q] + oL[q] : oH[q];
+                    const float inv = 1.0f / (LO ? lH[q][0] + lL[q][0] : lH[q][0]);
                     f32x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {            // O[d] = row d + row 8+d: the other half-wave's value
@@ -406,7 +418,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         // ---- fc, k-block u (the 4 heads just finished): acc += Wfc[:, 32u : 32u+32] * O^T
         HL ob[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q], one);
+        for (int q = 0; q < NQ; ++q) ob[q] = split8<LO>(opair[0][q], opair[1][q], one);
             load_unit(fb, ws); WS_ADVP(1024, 8192);                // Wfc(u), m-tiles 2-3
         SB_GEMM();
 #pragma unroll
@@ -418,10 +430,12 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 const int mt = 2 * half + mm;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].hi, acc[q][mt]);
+                if (LO) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].lo, acc[q][mt]);
+                    for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].lo, acc[q][mt]);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wl, ob[q].hi, acc[q][mt]);
+                    for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wl, ob[q].hi, acc[q][mt]);
+                }
             }
             if (half == 0) {
                 SB_GEMM();
@@ -446,7 +460,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     DIAG_STAMP(4);
     HL x1b[NQ][2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1], one); x1b[q][1] = split8(acc[q][2], acc[q][3], one); }
+    for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8<LO>(acc[q][0], acc[q][1], one); x1b[q][1] = split8<LO>(acc[q][2], acc[q][3], one); }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
@@ -466,7 +480,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
             load_unit(ring[(mt + RM) & RM], ws); WS_ADVP(1024, 16384);
             SB_GEMM();
-            mm_unit_h<NQ>(t, ring[mt & RM], x1b);
+            mm_unit_h<NQ, LO>(t, ring[mt & RM], x1b);
             SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -475,7 +489,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         }
         HL hb[NQ][2];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1], one); hb[q][1] = split8(hid[q][2], hid[q][3], one); }
+        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8<LO>(hid[q][0], hid[q][1], one); hb[q][1] = split8<LO>(hid[q][2], hid[q][3], one); }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
             f32x4 t[NQ];
@@ -483,7 +497,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
             load_unit(ring[(mt + RM) & RM], ws); WS_ADVP(1024, 16384);
             SB_GEMM();
-            mm_unit_h<NQ>(t, ring[mt & RM], hb);
+            mm_unit_h<NQ, LO>(t, ring[mt & RM], hb);
             SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
 static constexpr int DEC_LDS_F32 = AttnLds<DEC_NKT>::BYTES;
 static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>::BYTES;
 
-template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h)
+template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h), 3: the same block with single f16 products
 __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
     const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
     const float* __restrict__ ws_sigma, const int* __restrict__ dur, int n_chunks, long long first_chunk, ParamsDev P,
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
         if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
+        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
         else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
     }
 
@@ -509,7 +510,7 @@ const char* check_cfg(const s2s_config* c) {
     if (c->encoder_layers < 1 || c->encoder_layers > S2S_MAX_LAYERS) return "encoder_layers must be 1..4";
     if (c->decoder_layers < 1 || c->decoder_layers > S2S_MAX_LAYERS) return "decoder_layers must be 1..4";
     if (c->pre_layers < 0 || c->pre_layers > S2S_MAX_LAYERS) return "pre_layers must be 0..4";
-    if (c->compute_mode != S2S_MODE_F32 && c->compute_mode != S2S_MODE_F16X3 && c->compute_mode != S2S_MODE_F16X3W) return "compute_mode must be S2S_MODE_F32, S2S_MODE_F16X3 or S2S_MODE_F16X3W";
+    if (c->compute_mode < S2S_MODE_F32 || c->compute_mode > S2S_MODE_F16) return "compute_mode must be S2S_MODE_F32, S2S_MODE_F16X3, S2S_MODE_F16X3W or S2S_MODE_F16";
     return nullptr;
 }
 
@@ -785,6 +786,9 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  DEC_LDS_H)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute(decoder LDS, f16 block)");
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 DEC_LDS_H)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute(decoder LDS, f16 single-product block)");
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel_w), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  AttnLdsW::BYTES)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute(decoder LDS, wide f16 block)");
@@ -851,6 +855,11 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
         }
         if (h->cfg.compute_mode == S2S_MODE_F16X3W)
             hipLaunchKernelGGL(s2s_decoder_kernel_w, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), AttnLdsW::BYTES, stream,
+                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
+                               P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
+                               (long long)s);
+        else if (h->cfg.compute_mode == S2S_MODE_F16)
+            hipLaunchKernelGGL(s2s_decoder_kernel<3>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
                                h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
                                P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
                                (long long)s);

@@ -413,3 +413,27 @@ def test_other_layer_counts(mode, enc_l, dec_l, pre_l):
     assert np.array_equal(y == 0, r == 0)
     assert np.abs(y - r).mean() < MAE_TOL * max(1, dec_l / 2) and np.abs(y - r).max() < MAX_TOL * max(1, dec_l / 2)
     eng.close()
+
+
+@pytest.mark.parametrize("tag", ["k9", "k6"])
+def test_reduced_precision_f16_mode(tag):
+    """S2S_MODE_F16 (decoder operands rounded to f16 once, one MFMA product per product; the precision class of the
+    reference's own fp16-autocast GPU path, inference.py:404) is OUTSIDE the 1e-4 pA parity bound by design.  What it
+    must keep: dwell indices bit-exact (the frontend stays f16x3), signal MAE < 0.05 pA / max < 0.5 pA against the fp32
+    goldens, and the zero pattern except where the pre-ReLU value is within that error of zero."""
+    sd, cfg = load_ckpt(tag)
+    g = load_npz(f"stages_{tag}.npz")
+    bases, nv = chunker.codes_to_bases(g["codes"])
+    eng = S.Engine(sd, cfg, mode="f16")
+    ref = S.Engine(sd, cfg, mode="f16x3")
+    b, n = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda()
+    kw = dict(inject_g=torch.from_numpy(g["g"]).cuda(), inject_z01=torch.from_numpy(np.ascontiguousarray(g["z01"])).cuda())
+    pp = S.PredictParams(**P())
+    a, r = eng.predict_chunks(b, n, pp, **kw), ref.predict_chunks(b, n, pp, **kw)
+    assert torch.equal(a["dur"], r["dur"])
+    y, t = a["signal"].cpu().numpy(), r["signal"].cpu().numpy()
+    same = (y == 0) == (t == 0)
+    assert same.mean() > 0.999
+    d = np.abs(y - t)[same]
+    assert 1e-4 < d.mean() < 0.05 and d.max() < 0.5            # measurably not the parity path, and bounded
+    eng.close(); ref.close()
