@@ -277,6 +277,19 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
     }
 }
 
+// A weight unit of the f16 streams: [kb0 hi][kb0 lo][kb1 hi][kb1 lo] (4 KiB), or, for the single-product mode, the hi-only
+// stream [kb0 hi][kb1 hi] (2 KiB) loaded into the same even slots.
+template <bool LO>
+__device__ __forceinline__ void load_unit_h(f32x4 (&f)[4], const float* __restrict__ ws) {
+    if (LO) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = ldg4(ws + i * 256);
+    } else {
+        f[0] = ldg4(ws); f[2] = ldg4(ws + 256);
+        f[1] = f32x4{0, 0, 0, 0}; f[3] = f32x4{0, 0, 0, 0};
+    }
+}
+
 // One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
 template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
@@ -289,9 +302,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
     _Float16* __restrict__ Vl = reinterpret_cast<_Float16*>(lds + G::K_BYTES);
     _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + wave * G::Q_WAVE_BYTES);
-    const float* ws = W + L.stream_h + lane * 4;
+    constexpr int UF = LO ? 1024 : 512;             // floats per weight unit: hi+lo fragments, or the hi-only stream
+    const float* ws = W + (LO ? L.stream_h : L.stream_f) + lane * 4;
     f32x4 fa[4], fb[4];
-    load_unit(fa, ws); WS_ADVP(1024, 2048);                    // Wk, pair 0
+    load_unit_h<LO>(fa, ws); WS_ADVP(UF, 2048);                    // Wk, pair 0
 
     HL xb[NQ][2];                                     // block input as B operands
 #pragma unroll
@@ -302,8 +316,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
-        if (S2S_ABL & 4096) { for (int i = 0; i < 4; ++i) fb[i] = fa[i]; } else load_unit(fb, ws);   // (4096: timing without this phase's loads)
-        WS_ADVP(1024, 2048);                                   // Wv, pair p
+        if (S2S_ABL & 4096) { for (int i = 0; i < 4; ++i) fb[i] = fa[i]; } else load_unit_h<LO>(fb, ws);   // (4096: timing without this phase's loads)
+        WS_ADVP(UF, 2048);                                   // Wv, pair p
         const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g);
         const float bv = W[L.bv + 16 * p + c];                 // V comes out transposed: this lane's column is one feature
         SB_GEMM();
@@ -314,8 +328,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
         mm_unit_h<NQ, LO>(ak, fa, xb);
         SB_GEMM();
-        if (!(S2S_ABL & 4096) || p == 3) load_unit(fa, ws);
-        WS_ADVP(1024, 2048);                                   // Wk, pair p+1 (after the last pair: Wq, pair 0)
+        if (!(S2S_ABL & 4096) || p == 3) load_unit_h<LO>(fa, ws);
+        WS_ADVP(UF, 2048);                                   // Wk, pair p+1 (after the last pair: Wq, pair 0)
         SB_GEMM();
         mm_unit_h_t<NQ, LO>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
         const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // K accumulator rows 4g..4g+3 = head, d0..d0+3
@@ -355,7 +369,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int pp = 0; pp < 2; ++pp) {
             const int p = 2 * u + pp;
             // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
-            if (pp == 0) { load_unit(fb, ws); WS_ADVP(1024, 8192); } else { load_unit(fa, ws); WS_ADVP(1024, 8192); }
+            if (pp == 0) { load_unit_h<LO>(fb, ws); WS_ADVP(UF, 8192); } else { load_unit_h<LO>(fa, ws); WS_ADVP(UF, 8192); }
             const f32x4 bq = ldg4(W + L.bq_nat + 16 * p + 4 * g);
             SB_GEMM();
             f32x4 qa[NQ];
@@ -419,7 +433,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         HL ob[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) ob[q] = split8<LO>(opair[0][q], opair[1][q], one);
-            load_unit(fb, ws); WS_ADVP(1024, 8192);                // Wfc(u), m-tiles 2-3
+            load_unit_h<LO>(fb, ws); WS_ADVP(UF, 8192);                // Wfc(u), m-tiles 2-3
         SB_GEMM();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {        // unit = [mt a hi][mt a lo][mt b hi][mt b lo]
@@ -439,7 +453,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             }
             if (half == 0) {
                 SB_GEMM();
-                load_unit(fa, ws); WS_ADVP(1024, 8192);        // next iteration's Wq (after the last: W1 unit 0)
+                load_unit_h<LO>(fa, ws); WS_ADVP(UF, 8192);        // next iteration's Wq (after the last: W1 unit 0)
                 SB_GEMM();
             }
         }
@@ -454,7 +468,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     f32x4 ring[RD][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
-    if (RD == 4) { load_unit(ring[1], ws); load_unit(ring[2], ws + 1024); WS_ADVP(2048, 16384); }
+    if (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
     SB_GEMM();
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
     DIAG_STAMP(4);
@@ -478,7 +492,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
-            load_unit(ring[(mt + RM) & RM], ws); WS_ADVP(1024, 16384);
+            load_unit_h<LO>(ring[(mt + RM) & RM], ws); WS_ADVP(UF, 16384);
             SB_GEMM();
             mm_unit_h<NQ, LO>(t, ring[mt & RM], x1b);
             SB_GEMM();
@@ -495,7 +509,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
-            load_unit(ring[(mt + RM) & RM], ws); WS_ADVP(1024, 16384);
+            load_unit_h<LO>(ring[(mt + RM) & RM], ws); WS_ADVP(UF, 16384);
             SB_GEMM();
             mm_unit_h<NQ, LO>(t, ring[mt & RM], hb);
             SB_GEMM();

@@ -617,6 +617,12 @@ LayerOff pack_layer(Arena& A, const float*& p) {
         std::vector<float> raw(sh.size() / 2);
         std::memcpy(raw.data(), sh.data(), sh.size() * sizeof(_Float16));
         L.stream_h = A.put(raw.data(), raw.size());
+        // hi-only stream for the single-product mode: every even 512-half fragment of the stream above
+        std::vector<_Float16> sf;
+        for (size_t f0 = 0; f0 + 1024 <= sh.size(); f0 += 1024) sf.insert(sf.end(), sh.begin() + f0, sh.begin() + f0 + 512);
+        std::vector<float> rawf(sf.size() / 2);
+        std::memcpy(rawf.data(), sf.data(), sf.size() * sizeof(_Float16));
+        L.stream_f = A.put(rawf.data(), rawf.size());
     }
     L.bq_nat = A.put(bq, 64);
     L.bk_nat = A.put(bk, 64);
