@@ -257,10 +257,12 @@ def main():
             "metric": "signal samples/sec at 5 kb reads (padded [chunks x 250] samples the predict path emits)",
             "value": chunks_s * 250, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.mode == "f32" else "f16x3",
-            "dtype_note": ("f32-input MFMA" if a.mode == "f32" else
-                           "every operand split into two f16 halves, three f16 MFMA products per product, fp32 accumulate: "
-                           "fp32-class accuracy, see cpu_baseline.parity"),
+            "dtype": {"f32": "f32", "f16": "f16"}.get(a.mode, "f16x3"),
+            "dtype_note": {"f32": "f32-input MFMA",
+                           "f16": "REDUCED PRECISION (outside the 1e-4 pA parity bound): decoder operands rounded to f16 once, one "
+                                  "f16 MFMA product per product, fp32 accumulate; frontend f16x3"}.get(
+                a.mode, "every operand split into two f16 halves, three f16 MFMA products per product, fp32 accumulate: "
+                        "fp32-class accuracy, see cpu_baseline.parity"),
             "data": "synthetic",
             "config": {"mode": a.mode, "workload": f"{a.reads} synthetic reads x {READ_LEN} nt per GPU ({B} chunks/step/GPU), "
                                    "default noise+duration samplers, synthetic k=9 checkpoint",
@@ -273,8 +275,8 @@ def main():
                          "frac": (tflops / PEAK[a.mode]) if tflops else None, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, separate profiled run)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 1088 * cpl if cpl else None,
-                         "peak_note": ("f32-input MFMA peak" if a.mode == "f32" else
-                                       "dense f16 MFMA peak / 3 products per algorithmic product; achieved counts algorithmic flops"),
+                         "peak_note": {"f32": "f32-input MFMA peak", "f16": "dense f16 MFMA peak"}.get(
+                             a.mode, "dense f16 MFMA peak / 3 products per algorithmic product; achieved counts algorithmic flops"),
                          "flop_per_chunk": FLOP_PER_CHUNK_DECODER,
                          "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                          "launches": dec_launches, "chunks_per_launch": dec_chunks / dec_launches if dec_launches else None},
