@@ -8,11 +8,17 @@ min_duration 3), synthetic k=9 checkpoint.  With N>1 every rank runs the same am
 its own read shard (weak scaling, no data-path collective); RCCL is used only for the barrier
 and the max-over-ranks of the elapsed time.
 
+`python bench.py --gpus N` without a torchrun environment starts its N ranks itself, as CHILD processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`), before
+anything in the parent has touched the GPU, relays rank 0's JSON line and exits with the children's code.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +31,14 @@ sys.path.insert(0, ROOT)
 import seq2squiggle_amd as S  # noqa: E402
 
 FLOP_PER_CHUNK = 85_083_392            # 2 x 42,541,696 MAC, k = 9
-FLOP_PER_CHUNK_DECODER = 2 * 40_592_000  # decoder-side share (the dominant kernel), SURVEY.md section 2.2
+FLOP_PER_CHUNK_DOMINANT = 2 * 40_592_000  # decoder-side share (the dominant kernel), SURVEY.md section 2.2
+DOMINANT_KERNEL = "s2s_decoder_kernel"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA
-# f16x3 evaluates every algorithmic product as three f16 MFMA products (hi*hi + hi*lo + lo*hi), so
-# the matrix-core ceiling for ALGORITHMIC flops is a third of the dense f16 peak.
-PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f16x3w": PEAK_F16_MFMA_TFLOPS / 3.0,
-        "f16": PEAK_F16_MFMA_TFLOPS}
+# roofline.frac is always quoted against the guide's dense peak of the MFMA dtype the mode issues.  (f16x3 evaluates every
+# algorithmic product as three f16 MFMA products, so its own ceiling for ALGORITHMIC flops is a third of that: reported
+# as the secondary field frac_of_f16x3_ceiling.)
+PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS}
 READ_LEN, CHUNKS_PER_READ = 5000, 312
 
 
@@ -42,20 +49,26 @@ def make_reads(n_reads, seed):
     return [lut[c].tobytes().decode() for c in codes]
 
 
-def pmc_traffic(mode, chunks_per_launch):
-    """HBM bytes per decoder launch from the committed PMC passes (tools/pmc_run.sh -> profiles/*/pmc_summary.json):
-    (2 x FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half of a wide coalesced read on gfx950
-    (MI355X_MICROARCH.md, HBM) -- measured per 32,768-chunk dispatch and scaled to this run's launch size."""
+def pmc_counters(mode, chunks_per_launch):
+    """From the newest committed PMC passes (tools/pmc_run.sh -> profiles/*/pmc_summary.json), for the decoder kernel:
+    HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half of a wide coalesced read on
+    gfx950 (MI355X_MICROARCH.md, HBM) -- measured on one full dispatch and scaled to this run's launch size; matrix-core
+    busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; vector issue fraction =
+    4 x SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 over the same cycles."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(path)).get(mode, {})
-            k = next(k for k in d if "decoder" in k)
-            per_chunk = (2 * d[k]["FETCH_SIZE"] + d[k]["WRITE_SIZE"]) * 1024 / 32768
-            return per_chunk * chunks_per_launch, os.path.relpath(path, ROOT)
+            k = next(k for k in d if "decoder" in k or "predict_kernel" in k)
+            c = d[k]
+            chunks = c.get("_launch", {}).get("chunks", 32768)
+            per_chunk = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / chunks
+            cyc = c["GRBM_GUI_ACTIVE"] / 8
+            return {"traffic": per_chunk * chunks_per_launch, "mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
+                    "valu_issue": 4 * c["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, "source": os.path.relpath(path, ROOT)}
         except Exception:
             continue
-    return None, None
+    return {"traffic": None, "mfma_busy": None, "valu_issue": None, "source": None}
 
 
 def end_to_end(mode):
@@ -175,23 +188,65 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
             "sample": f"{done} chunks (batches of 1024, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
 
 
+WORKLOADS = {"config2": 1000, "config3": 12500}     # reads per GPU: BASELINE.json configs[1] / configs[2] (100,000 reads over 8 GPUs)
+
+
+def launch_ranks(a, argv):
+    """`--gpus N` outside torchrun: start the N ranks as children of this (GPU-untouched) process and relay rank 0's line."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [x for x in argv if x != "--dry-launch"]
+    if a.dry_launch:
+        print(json.dumps({"dry_launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout.splitlines():
+        if line.startswith("{"):
+            print(line)
+        elif line.strip():
+            print(line, file=sys.stderr)
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1000)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS),
+                    help="reads per GPU and step: config2 = 1000 x 5 kb (BASELINE configs[1]), config3 = 12500 x 5 kb "
+                         "(configs[2]: each GPU's share of 100,000 reads over 8)")
+    ap.add_argument("--reads", type=int, default=None, help="override the workload's reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3", "f16x3w", "f16"],
+    ap.add_argument("--dry-launch", action="store_true", help="print the child command --gpus N would start, run nothing")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="CPU-only check of the launcher: the ranks meet over gloo, rank 0 prints {n_ranks_seen}, no GPU work")
+    ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3", "f16"],
                     help="decoder arithmetic: f32-input MFMA, or split-f16 (3 f16 MFMA products, fp32 accumulate)")
     a = ap.parse_args()
+    n_reads = a.reads if a.reads is not None else WORKLOADS[a.workload]
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.dry_launch):
+        sys.exit(launch_ranks(a, sys.argv[1:]))            # nothing above this line has initialised the GPU
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.launch_selftest:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_selftest": True, "n_gpus": a.gpus, "n_ranks_seen": dist.get_world_size(),
+                              "sum_of_ones": int(t.item())}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST"):      # (the env var exercises the RCCL calls on one GPU)
@@ -201,7 +256,7 @@ def main():
     sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
     eng = S.Engine(sd, cfg, device=local, mode=a.mode)
     dev = eng.device
-    reads = make_reads(a.reads, 1234 + rank)               # every rank: its own shard of the read set
+    reads = make_reads(n_reads, 1234 + rank)               # every rank: its own shard of the read set
     bases, nv, first = S.encode_reads(reads, cfg["seq_kmer"])
     B = bases.shape[0]
     bases_d, nv_d = torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev)
@@ -224,15 +279,22 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                         # this rank's own time, before waiting for the others
     if dist:
         dist.barrier()
     el = time.perf_counter() - t0
     eng.set_profiling(False)
     dec_ms, dec_launches, dec_chunks = eng.kernel_ms()
+    ranks_seen, per_rank = 1, [B * a.steps / own]
     if dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([B * a.steps / own], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
     emitted = int((sig != 0).sum().item())
     # the reference's default batch (1024 chunks per call), reported for transparency only; skipped with
     # --no-cpu-baseline so that a rocprofv3 --stats of that command averages the bench launches alone
@@ -250,9 +312,25 @@ def main():
     if rank == 0:
         chunks_total = B * a.steps * world
         chunks_s = chunks_total / el
-        tflops = FLOP_PER_CHUNK_DECODER * dec_chunks / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else None
+        tflops = FLOP_PER_CHUNK_DOMINANT * dec_chunks / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else None
         cpl = dec_chunks / dec_launches if dec_launches else None
-        traffic, traffic_src = pmc_traffic(a.mode, cpl) if cpl else (None, None)
+        pmc = pmc_counters(a.mode, cpl) if cpl else pmc_counters(a.mode, 0)
+        peak = PEAK[a.mode]
+        roof = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                "frac": (tflops / peak) if tflops else None, "traffic": pmc["traffic"],
+                "traffic_unit": "bytes per launch (PMC, separate profiled run)", "traffic_source": pmc["source"],
+                "mfma_busy": pmc["mfma_busy"], "valu_issue": pmc["valu_issue"],
+                "algorithmic_bytes_per_launch": 1088 * cpl if cpl else None,
+                "peak_note": {"f32": "f32-input MFMA peak (MI355X_MICROARCH.md)"}.get(
+                    a.mode, "dense f16 MFMA peak (MI355X_MICROARCH.md); achieved counts ALGORITHMIC flops"),
+                "flop_per_chunk": FLOP_PER_CHUNK_DOMINANT,
+                "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
+                "launches": dec_launches, "chunks_per_launch": cpl}
+        if a.mode == "f16x3" and tflops:
+            # secondary readings: every algorithmic product costs three f16 MFMA products in this arithmetic, and the
+            # native exact-f32 alternative is the f32-input MFMA
+            roof["frac_of_f16x3_ceiling"] = tflops / (PEAK_F16_MFMA_TFLOPS / 3.0)
+            roof["x_of_f32_mfma_peak"] = tflops / PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "signal samples/sec at 5 kb reads (padded [chunks x 250] samples the predict path emits)",
             "value": chunks_s * 250, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -264,22 +342,14 @@ def main():
                 a.mode, "every operand split into two f16 halves, three f16 MFMA products per product, fp32 accumulate: "
                         "fp32-class accuracy, see cpu_baseline.parity"),
             "data": "synthetic",
-            "config": {"mode": a.mode, "workload": f"{a.reads} synthetic reads x {READ_LEN} nt per GPU ({B} chunks/step/GPU), "
+            "config": {"mode": a.mode, "workload": f"{n_reads} synthetic reads x {READ_LEN} nt per GPU ({B} chunks/step/GPU), "
                                    "default noise+duration samplers, synthetic k=9 checkpoint",
                        "chunks_per_step_per_gpu": B, "profile": "dna-r10-prom", "seed": 42},
+            "n_ranks_seen": ranks_seen, "per_rank_chunks_per_sec": per_rank,
             "reads_per_sec": chunks_s / CHUNKS_PER_READ, "chunks_per_sec": chunks_s,
             "emitted_samples_per_sec": emitted * world / (el / a.steps),
             "chunks_per_sec_at_reference_batch_1024": small_rate,
-            "roofline": {"bound": "mfma", "kernel": "s2s_decoder_kernel", "achieved": tflops,
-                         "peak": PEAK[a.mode], "unit": "TFLOP/s",
-                         "frac": (tflops / PEAK[a.mode]) if tflops else None, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, separate profiled run)", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": 1088 * cpl if cpl else None,
-                         "peak_note": {"f32": "f32-input MFMA peak", "f16": "dense f16 MFMA peak"}.get(
-                             a.mode, "dense f16 MFMA peak / 3 products per algorithmic product; achieved counts algorithmic flops"),
-                         "flop_per_chunk": FLOP_PER_CHUNK_DECODER,
-                         "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
-                         "launches": dec_launches, "chunks_per_launch": dec_chunks / dec_launches if dec_launches else None},
+            "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["end_to_end"] = end_to_end(a.mode)

@@ -30,13 +30,13 @@ extern "C" {
 #define S2S_ERR_HIP (-2)     /* a HIP runtime call failed                 */
 #define S2S_ERR_BLOB (-3)    /* weight blob has the wrong size            */
 
-/* Decoder arithmetic.  F32, F16X3 and F16X3W stay inside the 1e-4 pA MAE parity bound.
+/* Decoder arithmetic.  F32 and F16X3 stay inside the 1e-4 pA MAE parity bound.
  *   S2S_MODE_F32    every product on the f32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32;
  *   S2S_MODE_F16X3  operands split into two f16 halves (22 bits), three f16 MFMA products with
  *                   fp32 accumulation per original product (v_mfma_f32_16x16x32_f16). */
 #define S2S_MODE_F32 0
 #define S2S_MODE_F16X3 1
-#define S2S_MODE_F16X3W 2   /* same arithmetic as F16X3, decoder tiled for v_mfma_f32_32x32x16_f16 */
+/* (value 2 is retired: a 32x32x16-tiled variant of F16X3 that never beat it) */
 #define S2S_MODE_F16 3      /* REDUCED PRECISION, outside the 1e-4 pA bound: decoder operands rounded to f16 once (the
                              * precision class of the reference's own fp16-autocast GPU path, inference.py:404), one MFMA
                              * product per product; the frontend stays F16X3, so dwell indices remain bit-exact */

@@ -4,7 +4,14 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "s2s_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "s2s_device.h"), os.path.join(os.path.dirname(HERE), "include", "s2s_hip.h")]
+
+
+def deps():
+    """Every file the library is compiled from: csrc/*.hip, csrc/*.h, include/*.h."""
+    import glob
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.h")) +
+                  glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
+
 LIB = os.path.join(HERE, "lib", "libs2s_hip.so")
 
 
@@ -12,7 +19,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -5,6 +5,8 @@ ckpt["hyper_parameters"] and ckpt["state_dict"]; ModelCheckpoint(save_weights_on
 (train.py:81-87) writes them.  Here the file is read with plain torch.load and flattened
 into the fp32 blob of include/s2s_hip.h (s2s_blob_floats documents the order).
 """
+import os
+import pickle
 from typing import Dict, Tuple
 
 import numpy as np
@@ -19,9 +21,22 @@ _LAYER = ("slf_attn.w_qs.weight", "slf_attn.w_qs.bias", "slf_attn.w_ks.weight", 
 _MLP = ("0.weight", "0.bias", "3.weight", "3.bias")
 
 
-def load_checkpoint(path: str) -> Tuple[Dict[str, torch.Tensor], dict]:
-    """-> (state_dict, config).  Only `state_dict` and `hyper_parameters["config"]` are required."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+def load_checkpoint(path: str, allow_pickle: bool = None) -> Tuple[Dict[str, torch.Tensor], dict]:
+    """-> (state_dict, config).  Only `state_dict` and `hyper_parameters["config"]` are required.
+
+    The file is read with torch's restricted unpickler (tensors, plain dicts, lists and scalars: all a
+    ModelCheckpoint(save_weights_only=True) file holds).  A checkpoint that carries other pickled objects is refused
+    unless the caller opts into full unpickling (allow_pickle=True or S2S_ALLOW_PICKLE=1): that executes code
+    from the file."""
+    if allow_pickle is None:
+        allow_pickle = os.environ.get("S2S_ALLOW_PICKLE", "") == "1"
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not allow_pickle:
+            raise ValueError(f"{path}: holds pickled objects beyond tensors and plain containers ({e}); "
+                             "set S2S_ALLOW_PICKLE=1 to unpickle it anyway (this runs code from the file)") from e
+        ck = torch.load(path, map_location="cpu", weights_only=False)
     if "state_dict" not in ck:
         raise ValueError(f"{path}: not a seq2squiggle checkpoint (no 'state_dict')")
     cfg = (ck.get("hyper_parameters") or {}).get("config")
@@ -53,7 +68,7 @@ def state_dict_to_blob(sd: Dict[str, torch.Tensor], cfg: dict) -> np.ndarray:
     return np.concatenate([sd[n].detach().float().cpu().numpy().ravel() for n in blob_names(cfg)]).astype(np.float32)
 
 
-MODES = {"f32": 0, "f16x3": 1, "f16x3w": 2, "f16": 3}     # f16: reduced precision (see include/s2s_hip.h)
+MODES = {"f32": 0, "f16x3": 1, "f16": 3}     # f16: reduced precision (see include/s2s_hip.h)
 
 
 def config_to_c(cfg: dict, mode: str = "f16x3") -> S2SConfig:

@@ -19,7 +19,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct LayerOff {
     int stream;                             // packed A fragments in consumption order (float offset into the arena)
     int stream_h;                           // the same units as f16 hi/lo fragments (s2s_device_h.h)
-    int stream_w;                           // f16 hi/lo fragments for the 32x32x16 geometry (s2s_device_w.h)
     int stream_f;                           // the hi fragments of stream_h only (S2S_MODE_F16)
     int bq, bk, bv, bfc, b1, b2;            // biases (bq/bk in the q/k row permutation)
     int bq_nat, bk_nat;                     // bq/bk in natural row order (f16 block)

@@ -468,7 +468,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     f32x4 ring[RD][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
-    if (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
+    if constexpr (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
     SB_GEMM();
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
     DIAG_STAMP(4);

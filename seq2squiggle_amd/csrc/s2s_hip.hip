@@ -10,7 +10,6 @@
 // plus s2s_export_* for the per-read zero-strip / int16 conversion.
 #include "s2s_device.h"
 #include "s2s_device_h.h"
-#include "s2s_device_w.h"
 #include "../../include/s2s_hip.h"
 
 #include <cstdio>
@@ -213,7 +212,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
     {
         int run = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { run += dur[b * 16 + j]; cum[j] = run; }
+        for (int j = 0; j < 16; ++j) {          // a dwell past the crop at 250 (modules.py:386) acts like 251: no int32 overflow
+            const int dj = dur[b * 16 + j];
+            run += dj < S2S_T_DEC + 1 ? dj : S2S_T_DEC + 1;
+            cum[j] = run;
+        }
     }
     f32x4 X[DEC_NQ][4];
     float sig_ext[DEC_NQ];
@@ -281,82 +284,6 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
     }
     DIAG_STAMP(9);
     }   // chunk loop
-}
-
-// The same decoder in the 32x32x16 MFMA geometry (s2s_device_w.h): wave w owns time columns 32w .. 32w+31 as
-// ONE tile; lane (h = lane>>5, c = lane&31) holds feature 32T + 8(r>>2) + 4h + (r&3) of column c in register r.
-__global__ __launch_bounds__(DEC_WAVES * 64, 2) void s2s_decoder_kernel_w(
-    const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
-    const float* __restrict__ ws_sigma, const int* __restrict__ dur, int n_chunks, long long first_chunk, ParamsDev P,
-    const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
-    asm volatile("" : "+s"(one));
-#pragma unroll 1
-    for (int b = blockIdx.x; b < n_chunks; b += gridDim.x) {
-#ifdef S2S_DIAG
-        unsigned long long* diag_buf = dbg.diag;
-#endif
-        DIAG_DECL;
-        // ---- length regulator gather (modules.py:344-392) + position_enc (modules.py:136)
-        const int t = 32 * wave + c;
-        int idx = 0;
-        {
-            int run = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { run += dur[b * 16 + j]; idx += (run <= t) ? 1 : 0; }
-        }
-        const bool live = idx < 16, real = t < S2S_T_DEC;
-        const float* er = ws_enc + ((size_t)b * 16 + (live ? idx : 0)) * 64 + 4 * h;
-        const float* pr = W + M.pe_dec + (real ? t : 0) * 64 + 4 * h;
-        f32x16 X[2];
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const f32x4 e = ldg4(er + 32 * T + 8 * rr), pe = ldg4(pr + 32 * T + 8 * rr);
-                const f32x4 v = real ? ((live ? e : f32x4{0, 0, 0, 0}) + pe) : f32x4{0, 0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) X[T][4 * rr + j] = v[j];
-            }
-        const float sig_ext = live ? ws_sigma[b * 16 + (live ? idx : 0)] : 0.0f;
-        DIAG_STAMP(8);
-#pragma unroll 1
-        for (int l = 0; l < M.dec_layers; ++l) fft_block_w<S2S_T_DEC>(W, M.dec[l], X, lds_raw, wave, lane, one, dbg.diag);
-        DIAG_STAMP(15);
-        // ---- out_linear + ReLU (modules.py:140-141), x165 (model.py:221), noise where != 0, clamp (model.py:224-240)
-        float part = 0.0f;
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            const f32x16 wo = rowvec(W + M.out_w, T, h);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part += X[T][r] * wo[r];
-        }
-        const float ys = fmaxf(sum_h(part) + W[M.out_b], 0.0f);
-        float y = __fmul_rn(ys, M.scale);
-        if (h == 0 && real) {
-            if (dbg.y_scaled) dbg.y_scaled[(dbg_base + b) * S2S_T_DEC + t] = ys;
-            if (P.noise_std > 0.0f) {
-                float z;
-                if (inj_z01) {
-                    z = inj_z01[(size_t)b * S2S_T_DEC + t];
-                } else {
-                    const unsigned long long chunk = (unsigned long long)(first_chunk + b);
-                    const u32x4 r = philox4x32_10((unsigned)chunk, (unsigned)(chunk >> 32),
-                                                  (unsigned)t | (S2S_KIND_NOISE << 16), 0, P.seed_lo, P.seed_hi);
-                    z = box_muller(r.x, r.y);
-                }
-                if (dbg.z01) dbg.z01[(dbg_base + b) * S2S_T_DEC + t] = z;
-                const float sd = P.noise_sampling ? __fmul_rn(__fmul_rn(fmaxf(sig_ext, P.min_noise), P.noise_std), M.scale)
-                                                  : P.noise_std;
-                if (y != 0.0f) y = __fadd_rn(y, __fmul_rn(z, sd));
-            }
-            out_signal[(size_t)b * S2S_T_DEC + t] = fmaxf(y, 0.0f);
-        }
-        DIAG_STAMP(9);
-    }
 }
 
 // ================================================================================ export
@@ -510,7 +437,8 @@ const char* check_cfg(const s2s_config* c) {
     if (c->encoder_layers < 1 || c->encoder_layers > S2S_MAX_LAYERS) return "encoder_layers must be 1..4";
     if (c->decoder_layers < 1 || c->decoder_layers > S2S_MAX_LAYERS) return "decoder_layers must be 1..4";
     if (c->pre_layers < 0 || c->pre_layers > S2S_MAX_LAYERS) return "pre_layers must be 0..4";
-    if (c->compute_mode < S2S_MODE_F32 || c->compute_mode > S2S_MODE_F16) return "compute_mode must be S2S_MODE_F32, S2S_MODE_F16X3, S2S_MODE_F16X3W or S2S_MODE_F16";
+    if (c->compute_mode != S2S_MODE_F32 && c->compute_mode != S2S_MODE_F16X3 && c->compute_mode != S2S_MODE_F16)
+        return "compute_mode must be S2S_MODE_F32, S2S_MODE_F16X3 or S2S_MODE_F16";
     return nullptr;
 }
 
@@ -626,38 +554,6 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     }
     L.bq_nat = A.put(bq, 64);
     L.bk_nat = A.put(bk, 64);
-    // 32x32x16 geometry (s2s_device_w.h): per (32-row m-tile, k-block of 16) a hi and a lo fragment of 64 lanes x 8
-    // halves; lane (h, i), element j: W[32mt + i][kbase + 8(j>>2) + 4h + (j&3)]; unit = 4 k-blocks = 8 KiB
-    std::vector<_Float16> sw;
-    auto frag_w = [&](const float* Wm, int K, int mt, int kbase, bool lo) {
-        for (int lane = 0; lane < 64; ++lane) {
-            const int hh = lane >> 5, i = lane & 31;
-            for (int j = 0; j < 8; ++j) {
-                const float w = Wm[(size_t)(32 * mt + i) * K + kbase + 8 * (j >> 2) + 4 * hh + (j & 3)];
-                const _Float16 hi = (_Float16)w;
-                sw.push_back(lo ? (_Float16)(w - (float)hi) : hi);
-            }
-        }
-    };
-    auto unit_w = [&](const float* Wm, int K, int mt, int kbase) {
-        for (int kb = 0; kb < 4; ++kb) { frag_w(Wm, K, mt, kbase + 16 * kb, false); frag_w(Wm, K, mt, kbase + 16 * kb, true); }
-    };
-    unit_w(wk, 64, 0, 0); unit_w(wk, 64, 1, 0); unit_w(wv, 64, 0, 0); unit_w(wv, 64, 1, 0);
-    for (int grp = 0; grp < 2; ++grp) {
-        unit_w(wq, 64, grp, 0);
-        for (int mt = 0; mt < 2; ++mt)
-            for (int pp = 0; pp < 2; ++pp) { frag_w(wfc, 64, mt, 32 * grp + 16 * pp, false); frag_w(wfc, 64, mt, 32 * grp + 16 * pp, true); }
-    }
-    for (int hc = 0; hc < 4; ++hc) {
-        unit_w(w1, 64, 2 * hc, 0); unit_w(w1, 64, 2 * hc + 1, 0);
-        unit_w(w2, 256, 0, 64 * hc); unit_w(w2, 256, 1, 64 * hc);
-    }
-    sw.resize(sw.size() + 3 * 4096, (_Float16)0.0f);       // prefetches run up to two units past the end
-    {
-        std::vector<float> raw(sw.size() / 2);
-        std::memcpy(raw.data(), sw.data(), sw.size() * sizeof(_Float16));
-        L.stream_w = A.put(raw.data(), raw.size());
-    }
     L.bq = A.put_bias_perm(bq, 64);
     L.bk = A.put_bias_perm(bk, 64);
     L.bv = A.put(bv, 64);
@@ -795,9 +691,6 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  DEC_LDS_H)) != hipSuccess)
         return bail(e, "hipFuncSetAttribute(decoder LDS, f16 single-product block)");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel_w), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 AttnLdsW::BYTES)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute(decoder LDS, wide f16 block)");
 #ifdef S2S_DIAG
     if ((e = hipMalloc(&h->d_diag, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
     if ((e = hipMemset(h->d_diag, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
@@ -859,12 +752,7 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
             HIP_TRY(h, hipEventCreate(&ev.b));
             HIP_TRY(h, hipEventRecord(ev.a, stream));
         }
-        if (h->cfg.compute_mode == S2S_MODE_F16X3W)
-            hipLaunchKernelGGL(s2s_decoder_kernel_w, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), AttnLdsW::BYTES, stream,
-                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
-                               P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
-                               (long long)s);
-        else if (h->cfg.compute_mode == S2S_MODE_F16)
+        if (h->cfg.compute_mode == S2S_MODE_F16)
             hipLaunchKernelGGL(s2s_decoder_kernel<3>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
                                h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
                                P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,

@@ -107,6 +107,10 @@ class Engine:
                 raise ValueError(f"{name} must be contiguous float32 {shape} on {self.device}")
         if bases.device != self.device or n_valid.device != self.device:
             raise ValueError(f"inputs must live on {self.device}")
+        for name, t, dt, shape in (("out_signal", out_signal, torch.float32, (B, T_DEC)),
+                                   ("out_dur", out_dur, torch.int32, (B, T_ENC))):
+            if t is not None and (t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device):
+                raise ValueError(f"{name} must be contiguous {dt} {shape} on {self.device}")
         sig = out_signal if out_signal is not None else torch.empty(B, T_DEC, dtype=torch.float32, device=self.device)
         dur = out_dur if out_dur is not None else torch.empty(B, T_ENC, dtype=torch.int32, device=self.device)
         out = {"signal": sig, "dur": dur}
@@ -155,8 +159,10 @@ class Engine:
         B, R = int(signal.shape[0]), int(read_first.shape[0]) - 1
         if signal.dtype != torch.float32 or not signal.is_contiguous() or signal.shape[1] != T_DEC:
             raise ValueError("signal must be contiguous float32 [B,250]")
-        if read_first.dtype != torch.int32 or not read_first.is_contiguous():
+        if read_first.dtype != torch.int32 or not read_first.is_contiguous() or read_first.dim() != 1 or R < 0:
             raise ValueError("read_first must be contiguous int32 [R+1]")
+        if signal.device != self.device or read_first.device != self.device:
+            raise ValueError(f"signal and read_first must live on {self.device}")
         offs = torch.empty(R + 1, dtype=torch.int64, device=self.device)
         cap = B * T_DEC
         pa = torch.empty(cap, dtype=torch.float32, device=self.device) if want_pa else None

@@ -21,7 +21,7 @@ def golden_dir():
 
 
 def load_ckpt(tag):
-    ck = torch.load(os.path.join(GOLDEN, f"synthetic_{tag}.ckpt"), map_location="cpu", weights_only=False)
+    ck = torch.load(os.path.join(GOLDEN, f"synthetic_{tag}.ckpt"), map_location="cpu", weights_only=True)
     return ck["state_dict"], ck["hyper_parameters"]["config"]
 
 

@@ -206,6 +206,9 @@ def test_bench_contract_line():
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["avg_launch_ms"] > 0
+    assert rf["peak"] == 2500.0                       # the guide's dense f16 peak, not a derated one
+    assert abs(rf["frac_of_f16x3_ceiling"] - 3 * rf["frac"]) < 1e-9 and rf["x_of_f32_mfma_peak"] > 0
+    assert d["n_ranks_seen"] == 1 and len(d["per_rank_chunks_per_sec"]) == 1
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["parity"]["dwell_indices_equal"] and cb["parity"]["signal_mae_pa"] < cb["parity"]["tolerance_mae_pa"]
