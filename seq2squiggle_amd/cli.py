@@ -101,7 +101,8 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
     setup_logging(verbosity)
     logger.info("seq2squiggle (MI355X engine) version %s", str(__version__))
     cfg = set_config(config)
-    seed = set_seeds(seed)
+    from .parallel import shared_seed
+    seed = set_seeds(shared_seed(seed))        # --seed 0 under torchrun: rank 0's fresh seed, for every rank
     inference_run(config=cfg, saved_weights=model, fasta=str(fasta), read_input=read_input, n=num_reads, r=read_length,
                   c=coverage, out=str(out), profile=profile, dwell_mean=dwell_mean, dwell_std=dwell_std, noise_std=noise_std,
                   noise_sampling=noise_sampler, duration_sampling=duration_sampler, distr=distr,

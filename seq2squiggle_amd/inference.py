@@ -194,7 +194,10 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     if saved_weights is None:
         raise FileNotFoundError("no model weights given: downloading released weights needs network access; pass "
                                 "--model <file.ckpt>")
-    first_chunk = 0
+    first_chunk, first_read = 0, 0
+    if world > 1 and not seed:
+        raise ValueError("multi-process runs need one seed for all ranks: pass an explicit --seed, or let the CLI share a "
+                         "fresh one (parallel.shared_seed) before calling inference_run")
     if world > 1 and not read_input:
         # every rank replays the sampler for the read lengths, then builds only its own contiguous share of the reads
         from .utils import preprocess_genome, sample_read_shard
@@ -203,9 +206,10 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
 
         def shard_of(lens):
             lo, hi, picked["first"] = shard_reads(lens, config["seq_kmer"], world)[rank]
+            picked["lo"] = lo
             return lo, hi
         reads, lens = sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of)
-        first_chunk = picked["first"]
+        first_chunk, first_read = picked["first"], picked["lo"]
         logger.info(f"rank {rank}/{world}: {len(reads)} of {len(lens)} reads, first global chunk {first_chunk}")
     else:
         reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
@@ -213,8 +217,11 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
             reads = list(reads)
             lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
             reads = reads[lo:hi]
+            first_read = lo
             logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
 
+    if first_read:
+        writer.start_at(first_read)            # read ids / read_number / record draws continue the single-process run
     load_model = seq2squiggle.load_from_checkpoint(
         checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean, dwell_std=dwell_std, noise_std=noise_std,
         noise_sampling=noise_sampling, duration_sampling=duration_sampling, export_every_n_samples=export_every_n_samples,

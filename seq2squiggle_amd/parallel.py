@@ -38,3 +38,21 @@ def rank_output_path(out: str, rank: int, world: int) -> str:
         return out
     base, ext = os.path.splitext(out)
     return f"{base}.rank{rank}{ext}"
+
+
+def shared_seed(seed: int) -> int:
+    """One seed for every rank of a multi-process run.  An explicit seed is shared already; `--seed 0` means "draw a
+    fresh one" (utils.py:722-741), which each process would do on its own -- different read sets, shard bounds and RNG
+    keys per rank.  Rank 0 draws it and the others receive it over a short-lived gloo group (host side, no GPU)."""
+    rank, _, world = rank_world()
+    if world == 1 or seed:
+        return seed
+    import torch.distributed as dist
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo")
+    box = [int.from_bytes(os.urandom(4), "big") or 1 if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if created:
+        dist.destroy_process_group()
+    return int(box[0])

@@ -68,6 +68,15 @@ def _fmt_double(x: float) -> str:
     return repr(float(x))
 
 
+def _skip_record_draws(n_reads: int) -> None:
+    """Advance np.random past the per-read offset / median_before draws (two normals per read, signal_io.py:129-133) of the
+    `n_reads` reads that earlier rank shards own, so that a shard writer continues the single-process stream."""
+    for _ in range(n_reads // 65536):
+        np.random.normal(size=2 * 65536)
+    if n_reads % 65536:
+        np.random.normal(size=2 * (n_reads % 65536))
+
+
 class BLOW5Writer:
     """Writes `.slow5` (ASCII) or `.blow5` (binary) by the file extension."""
 
@@ -91,6 +100,16 @@ class BLOW5Writer:
         self.binary = self.filename.endswith(".blow5")
         self.compress_level = 1               # zlib level of BLOW5 records; any level is a valid zlib stream
         self._pool = None
+
+    def start_at(self, read_index: int) -> None:
+        """Rank shards (parallel.py): this writer's first read is read `read_index` of the whole job, so read ids and
+        read_number continue from there and the record draws continue the single-process np.random stream (exact as long
+        as no earlier read came out empty).  start_time stays per file."""
+        if self.n_written:
+            raise RuntimeError("start_at() must come before the first record")
+        self.n_written = int(read_index)
+        if not self.ideal_mode:
+            _skip_record_draws(int(read_index))
 
     # ------------------------------------------------------------------ header
     def header_attributes(self) -> dict:
@@ -286,6 +305,14 @@ class POD5Writer:
         self.start_time = 0
         self._stream, self._stream_idx, self._stream_run_info = None, 0, None
 
+    def start_at(self, read_index: int) -> None:
+        """Rank shards: see BLOW5Writer.start_at (streaming path: read ids / read_number continue from read_index)."""
+        if self._stream_idx:
+            raise RuntimeError("start_at() must come before the first record")
+        self._stream_idx = int(read_index)
+        if not self.ideal_mode:
+            _skip_record_draws(int(read_index))
+
     def run_info(self) -> dict:
         """signal_io.py:210-231."""
         seq_kit, flow_cell = get_seq_kit_and_flow_cell(self.profile_name)
@@ -314,7 +341,7 @@ class POD5Writer:
         rna = self.profile_name.startswith("rna")
         run_info = self.run_info()
         recs = []
-        for idx, (read_id, signal) in enumerate(self.signals.items()):
+        for idx, (read_id, signal) in enumerate(self.signals.items(), start=self._stream_idx):   # (start_at: rank shards)
             if len(signal) == 0:
                 logger.debug("Empty signal, skipping {}".format(read_id))
                 continue

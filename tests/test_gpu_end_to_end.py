@@ -263,3 +263,8 @@ def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
     assert len(parts) == len(one) == 30
     for a, b in zip(parts, one):
         assert np.array_equal(a["signal"], b["signal"])
+        # the shard files merge without collisions: ids, read numbers and the per-read offset / median_before draws are
+        # those of the single-process run (start_time is per file)
+        assert a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
+        assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
+    assert len({r["read_id"] for r in parts}) == 30

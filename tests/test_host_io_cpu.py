@@ -261,15 +261,75 @@ dist.destroy_process_group()
 """
 
 
+def _free_port() -> str:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def test_two_rank_sharding_over_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_DIST_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT,
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT,
                         os.path.join(GOLDEN, "example_lambda_genome.fasta")], capture_output=True, text=True, env=env,
                        timeout=300)
     assert "SHARDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_shard_writers_continue_the_single_process_run(tmp_path):
+    """rank shard files must merge without duplicate ids -- a writer started at read index lo numbers its
+    reads from lo and continues the np.random stream of the offset / median_before draws."""
+    prof = U.get_profile("dna-r10-prom")
+    sigs = [np.arange(1, 5 + i, dtype=np.int16) for i in range(7)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in sigs])])
+    flat = np.concatenate(sigs)
+    for cls, ext in ((signal_io.BLOW5Writer, "blow5"), (signal_io.POD5Writer, "pod5")):
+        np.random.seed(11)
+        one = cls(str(tmp_path / f"one.{ext}"), prof, False, "dna-r10-prom", False).dac_records([f"r{i}" for i in range(7)], flat, offs)
+        parts = []
+        for lo, hi in ((0, 3), (3, 7)):
+            np.random.seed(11)                                   # every rank process seeds the same way
+            w = cls(str(tmp_path / f"p{lo}.{ext}"), prof, False, "dna-r10-prom", False)
+            if lo:
+                w.start_at(lo)
+            parts += w.dac_records([f"r{i}" for i in range(lo, hi)], flat[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo])
+        assert len(parts) == len(one) == 7
+        for a, b in zip(parts, one):
+            assert str(a["read_id"]) == str(b["read_id"]) and a["read_number"] == b["read_number"]
+            assert a.get("offset", a.get("calibration_offset")) == b.get("offset", b.get("calibration_offset"))
+            assert a["median_before"] == b["median_before"] and np.array_equal(a["signal"], b["signal"])
+        assert len({str(r["read_id"]) for r in parts}) == 7
+
+
+_SEED_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from seq2squiggle_amd import parallel
+s0 = parallel.shared_seed(0)
+assert s0 != 0 and parallel.shared_seed(77) == 77
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([s0], dtype=torch.int64)
+out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+dist.all_gather(out, t)
+if dist.get_rank() == 0:
+    assert all(int(o) == s0 for o in out), out
+    print("SEED_SHARED", s0)
+dist.destroy_process_group()
+"""
+
+
+def test_seed_zero_is_shared_between_ranks(tmp_path):
+    script = tmp_path / "s.py"
+    script.write_text(_SEED_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT],
+                       capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=300)
+    assert "SEED_SHARED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert parallel.shared_seed(0) == 0            # single process: left to set_seeds (utils.py:722-741)
 
 
 def test_cli_surface():
