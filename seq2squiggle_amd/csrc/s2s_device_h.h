@@ -383,19 +383,20 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) {
                 h4 hi, lo;
                 split4<LO>((qa[q] + bq) * c1, one, hi, lo);               // scores come out in log2 units
-                *reinterpret_cast<h4*>(Ql + (((q * 2 + 0) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = hi;
-                *reinterpret_cast<h4*>(Ql + (((q * 2 + 1) * 2 + (g >> 1)) * 16 + c) * 8 + 4 * (g & 1)) = lo;
+                *reinterpret_cast<h4*>(Ql + ((((g >> 1) * NQ + q) * 2 + 0) * 16 + c) * 8 + 4 * (g & 1)) = hi;   // [head of the pair][q][hi|lo][c][8 d]
+                *reinterpret_cast<h4*>(Ql + ((((g >> 1) * NQ + q) * 2 + 1) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
-            // (indexed by the lane-dependent select below, so hipcc keeps it in scratch: a deliberate parking spot -- every
-            //  register-resident formulation tried pushed the kernel over 256 VGPRs and spilled hot values instead)
-            f32x4 ohead[2][NQ];
+            // The pair's fc operand takes head 2p from lanes g < 2 and head 2p+1 from lanes g >= 2.  Head 2p's output is
+            // parked, for the lanes that will use it, in the first half of the wave's Q scratch (head 2p's Q^T, dead once
+            // qb has been read) instead of eight more live registers through the second head's softmax.
+            f32x4 ohead1[NQ];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int head = 2 * p + hh;
                 h8 qb[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    qb[q] = *reinterpret_cast<const h8*>(Ql + (((q * 2 + (g & 1)) * 2 + hh) * 16 + c) * 8);
+                    qb[q] = *reinterpret_cast<const h8*>(Ql + (((hh * NQ + q) * 2 + (g & 1)) * 16 + c) * 8);
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
@@ -423,11 +424,16 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         auto sw = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
                         o[r] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * inv;
                     }
-                    ohead[hh][q] = o;                      // lanes g and g^2 both hold d = 4(g&1) + r
+                    // lanes g and g^2 both hold d = 4(g&1) + r
+                    if (hh == 0) { if (g < 2) *reinterpret_cast<f32x4*>(Ql + (q * 32 + lane) * 8) = o; }
+                    else ohead1[q] = o;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) opair[pp][q] = (g < 2) ? ohead[0][q] : ohead[1][q];   // pair tile: row 4g+r
+            for (int q = 0; q < NQ; ++q) {                 // pair tile: row 4g+r
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(Ql + (q * 32 + (lane & 31)) * 8);
+                opair[pp][q] = (g < 2) ? o0 : ohead1[q];
+            }
         }
         // ---- fc, k-block u (the 4 heads just finished): acc += Wfc[:, 32u : 32u+32] * O^T
         HL ob[NQ];

@@ -310,6 +310,16 @@ def write_pod5(path: str, reads: List[dict], file_identifier: uuid.UUID = None, 
         w.add_reads(reads)
 
 
+def _signal_rows(sig) -> List[np.ndarray]:
+    """int16 samples of every signal-table row, as numpy views of the Arrow buffers (no Python ints)."""
+    rows = []
+    for ch in sig.column("signal").chunks:
+        offs = ch.offsets.to_numpy()
+        vals = ch.values.to_numpy(zero_copy_only=False)
+        rows.extend(vals[offs[i]:offs[i + 1]] for i in range(len(ch)))
+    return rows
+
+
 def read_pod5(path: str) -> dict:
     """Reader of the files written above (tests / round trip): -> dict(footer, run_info rows, reads with their signal)."""
     pa = _pa()
@@ -331,10 +341,10 @@ def read_pod5(path: str) -> dict:
             raise ValueError("embedded file is not followed by the section marker")
         tabs[e["content_type"]] = pa.ipc.open_file(io.BytesIO(data[e["offset"]: end])).read_all()
     sig, reads_t, run_t = tabs[CT_SIGNAL], tabs[CT_READS], tabs[CT_RUN_INFO]
-    sig_rows = sig.column("signal").to_pylist()
+    sig_rows = _signal_rows(sig)
     reads = []
     for row in reads_t.to_pylist():
-        raw = np.concatenate([np.asarray(sig_rows[i], np.int16) for i in row["signal"]]) if row["signal"] else np.zeros(0, np.int16)
+        raw = np.concatenate([sig_rows[i] for i in row["signal"]]) if row["signal"] else np.zeros(0, np.int16)
         row = dict(row, read_id=uuid.UUID(bytes=row["read_id"]), signal=raw)
         reads.append(row)
     return {"footer": footer, "schema_metadata": {k.decode(): v.decode() for k, v in reads_t.schema.metadata.items()},

@@ -231,9 +231,8 @@ def test_sampler_statistics(case):
     z = out["z01"].cpu().flatten()
     assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1.0) < 0.01
     assert abs((z ** 4).mean().item() - 3.0) < 0.15
-    # noise really is N(0, sd): signal - noiseless signal, normalised, where the noiseless sample is non-zero
-    clean = eng.predict_chunks(bt, nvt, S.PredictParams(**P(min_duration=0.0, seed=7, noise_std=0.0)))
-    assert torch.equal(clean["dur"], out["dur"])
+    # (the laws themselves -- KS tests incl. the alpha < 1 Gamma branch, and the bit-exact noise formula -- are held in
+    #  tests/test_gpu_samplers.py; this is the quick moment check that runs for every checkpoint x arithmetic mode)
 
 
 def test_export_zero_strip_and_dac(case):
