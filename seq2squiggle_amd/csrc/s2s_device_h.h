@@ -29,6 +29,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ALWAYS_RESCALE
 #define S2S_ALWAYS_RESCALE 0
 #endif
+#ifndef S2S_FFN_LDS
+#define S2S_FFN_LDS 1           // decoder FFN weights staged once per workgroup in the dead K/V region (0: every wave streams them from L2)
+#endif
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
 // Scheduling barriers pin the weight-unit / K,V-fragment loads in front of the MFMAs they are prefetched behind; the
 // -DS2S_NO_SB_* builds measure what they are worth (the one in the attention pass: 15 % of the kernel).
@@ -111,7 +114,13 @@ __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h
 template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
     static constexpr int KEYS = 16 * NKT;
     static constexpr int K_BYTES = 8 * 2 * KEYS * 8 * 2;
-    static constexpr int VS = KEYS + 8;                   // halves per V row; 264: (VS/2) % 64 == 4 -> conflict-free b64 reads
+    // halves per V^T row.  NKT even (the decoder): a row is stored as [32-key block][lane group g][8 halves] -- the 4 keys 4g..4g+3 of
+    // the block's first tile, then those of its second -- so the P.V operand of a K = 32 block is ONE ds_read_b128 per lane;
+    // 272 halves = 136 dwords == 8 (mod 64) makes the 16 lanes of every b128 lane group hit 16 distinct 4-dword bank slots.
+    // (The natural key order needed two b64 reads, which hipcc fuses into ds_read2_b64: banked mod 32, 2-way conflicts on
+    // every access -- the 11,264 SQ_LDS_BANK_CONFLICT cycles per chunk of profiles/r01.)  NKT = 1 (encoder): natural order.
+    static constexpr bool V128 = (NKT % 2) == 0;
+    static constexpr int VS = V128 ? KEYS + 16 : KEYS + 8;
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
     static constexpr int BYTES = K_BYTES + V_BYTES + WAVES * Q_WAVE_BYTES;
@@ -196,10 +205,14 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
         for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
 #pragma unroll
         for (int kb = 0; kb < HB; ++kb) {
-            const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
-            h4 v1 = h4{0, 0, 0, 0};                        // a K = 32 block past the last key tile: zero keys
-            if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
-            va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (AttnLdsH<NQ, 1, NKT>::V128) {              // (vp already points at this lane group's 8 halves of block 0)
+                va[kb] = *reinterpret_cast<const h8*>(vp + 32 * (h2 * HB + kb));
+            } else {
+                const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
+                h4 v1 = h4{0, 0, 0, 0};                    // a K = 32 block past the last key tile: zero keys
+                if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
+                va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            }
         }
         SB_ATT();
         // all NQ time tiles go through a pass together, so that one tile's MFMAs can run
@@ -342,8 +355,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
             split4<LO>(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
-            *reinterpret_cast<h4*>(Vl + vrow * G::VS + 16 * (qt0 + q) + 4 * g) = hi;
-            *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + 16 * (qt0 + q) + 4 * g) = lo;
+            const int T = qt0 + q;                                    // (position inside the row: see AttnLdsH::VS)
+            const int vcol = G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;
+            *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
+            *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
         }
     }
     // ---- fc accumulator starts as bias + residual (layers.py:85-86)
@@ -398,7 +413,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 for (int q = 0; q < NQ; ++q)
                     qb[q] = *reinterpret_cast<const h8*>(Ql + (((hh * NQ + q) * 2 + (g & 1)) * 16 + c) * 8);
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
-                const _Float16* vp = Vl + (head * 16 + c) * G::VS + 4 * g;          // row c: 0-7 V_hi d, 8-15 V_lo d
+                const _Float16* vp = Vl + (head * 16 + c) * G::VS + (G::V128 ? 8 : 4) * g;   // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
                 softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
 #if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)   // (NO_FALLBACK: test-only build, proves test_peaked_attention... needs the redo)
@@ -464,7 +479,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             }
         }
     }
-    DIAG_STAMP(3);
+    if constexpr (!(S2S_FFN_LDS && WAVES == 8 && LO)) DIAG_STAMP(3);
 
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
     // A weight unit feeds only 6*NQ MFMAs (~200 cycles) here, less than an L2 round trip, so the stream
@@ -472,20 +487,64 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // (the one-wave frontend workgroups hide latency with occupancy instead: one unit ahead, 32 registers less)
     constexpr int RD = (NQ >= 2) ? 4 : 2, RM = RD - 1;               // ring depth; units in flight = RD - 1
     f32x4 ring[RD][4];
+    // FFN_LDS (the 8-wave decoder): every wave needs every FFN weight unit, and eight copies of the 128 KiB through the CU's
+    // 64 B/clk vector-L1 path cost more than the FFN's MFMAs (timing without these loads: +7.7 %).  The K/V region is dead
+    // once every wave has left the attention loop, so the workgroup copies the FFN stream into it ONCE -- wave w: unit
+    // 8hc + w of every slice hc, 16 KiB -- and the FFN reads its A fragments with ds_read_b128 (256 B/clk).  The copy goes
+    // through registers (global_load_dwordx4 issued before the barrier, ds_write_b128 after it): LDS-DMA lands at only
+    // ~12 B/clk per CU and cost 11 k cycles per layer when tried.  The next block's entry barrier protects the region again.
+    constexpr bool FFN_LDS = S2S_FFN_LDS && WAVES == 8 && LO && (G::K_BYTES + G::V_BYTES >= 32 * 4096);
+    const float* wl = reinterpret_cast<const float*>(lds) + lane * 4;    // this lane's 16 B of every staged 1-KiB fragment
+    if constexpr (FFN_LDS) {
+        f32x4 gm[4], bt[4], b2v[4], stage[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];                  // W1 unit 0 (requested during the last P.V)
-    if constexpr (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
-    SB_GEMM();
-    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
-    DIAG_STAMP(4);
+        for (int hc = 0; hc < 4; ++hc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage[4 * hc + i] = ldg4(ws + (8 * hc + wave - 1) * 1024 + i * 256);   // (ws is already one unit into the FFN)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            gm[ft] = ldg4(W + L.ln1g + 16 * ft + 4 * g); bt[ft] = ldg4(W + L.ln1b + 16 * ft + 4 * g);
+            b2v[ft] = ldg4(W + L.b2 + 16 * ft + 4 * g);
+        }
+        DIAG_STAMP(3);
+        __syncthreads();                                             // every wave is done reading K/V
+        DIAG_STAMP(12);
+        float* wst = reinterpret_cast<float*>(lds) + lane * 4;
+#pragma unroll
+        for (int hc = 0; hc < 4; ++hc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(wst + (8 * hc + wave) * 1024 + i * 256) = stage[4 * hc + i];
+        layer_norm64_r<NQ>(acc, gm, bt);                             // acc = x1
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b2v[mt];    // X = bias + residual accumulator
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];              // W1 unit 0 (requested during the last P.V)
+        if constexpr (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
+        SB_GEMM();
+        layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);            // acc = x1
+    }
+    if constexpr (!FFN_LDS) DIAG_STAMP(4);
     HL x1b[NQ][2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8<LO>(acc[q][0], acc[q][1], one); x1b[q][1] = split8<LO>(acc[q][2], acc[q][3], one); }
+    if constexpr (FFN_LDS) {
+        DIAG_STAMP(4);
+        __syncthreads();                                             // every wave's fragments are in LDS
+        DIAG_STAMP(14);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
+        for (int u = 0; u < RM; ++u)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;      // X = bias + residual accumulator
+            for (int i = 0; i < 4; ++i) ring[u][i] = ldg4(wl + u * 1024 + i * 256);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;  // X = bias + residual accumulator
+        }
     }
 #pragma unroll 1
     for (int hc = 0; hc < ((S2S_ABL & 128) ? 0 : 4); ++hc) {
@@ -498,7 +557,13 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
-            load_unit_h<LO>(ring[(mt + RM) & RM], ws); WS_ADVP(UF, 16384);
+            if constexpr (FFN_LDS) {                  // unit 8hc + mt + RM, three ahead of its use (wraps past the end: harmless)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring[(mt + RM) & RM][i] = ldg4(wl + ((8 * hc + mt + RM) & 31) * 1024 + i * 256);
+            } else {
+                if (!(S2S_ABL & 32768)) load_unit_h<LO>(ring[(mt + RM) & RM], ws);     // (32768: timing without the FFN's weight loads)
+                WS_ADVP(UF, 16384);
+            }
             SB_GEMM();
             mm_unit_h<NQ, LO>(t, ring[mt & RM], x1b);
             SB_GEMM();
@@ -515,7 +580,13 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
-            load_unit_h<LO>(ring[(mt + RM) & RM], ws); WS_ADVP(UF, 16384);
+            if constexpr (FFN_LDS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring[(mt + RM) & RM][i] = ldg4(wl + ((8 * hc + 4 + mt + RM) & 31) * 1024 + i * 256);
+            } else {
+                if (!(S2S_ABL & 32768)) load_unit_h<LO>(ring[(mt + RM) & RM], ws);
+                WS_ADVP(UF, 16384);
+            }
             SB_GEMM();
             mm_unit_h<NQ, LO>(t, ring[mt & RM], hb);
             SB_GEMM();

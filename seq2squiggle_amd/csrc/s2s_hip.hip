@@ -251,17 +251,23 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) wo[ft] = ldg4(W + M.out_w + 16 * ft + 4 * g);
     const float bo = W[M.out_b];
+    // every lane group ends up with the row sums of all tiles (sum_g is an all-reduce), so lane group q finishes tile q:
+    // ONE pass of Philox + Box-Muller per wave for its DEC_NQ <= 4 tiles
+    float ys = 0.0f, se = 0.0f;
 #pragma unroll
     for (int q = 0; q < DEC_NQ; ++q) {
-        const int t = 16 * (qt0 + q) + c;
         float part = 0.0f;
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part += X[q][ft][r] * wo[ft][r];
-        const float ys = fmaxf(sum_g(part) + bo, 0.0f);
+        const float v = fmaxf(sum_g(part) + bo, 0.0f);
+        if (g == q) { ys = v; se = sig_ext[q]; }
+    }
+    {
+        const int t = 16 * (qt0 + g) + c;
         float y = __fmul_rn(ys, M.scale);
-        if (g == 0 && t < S2S_T_DEC) {
+        if (g < DEC_NQ && t < S2S_T_DEC) {
             if (dbg.y_scaled) dbg.y_scaled[(dbg_base + b) * S2S_T_DEC + t] = ys;
             if (P.noise_std > 0.0f) {
                 float z;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
                 }
                 if (dbg.z01) dbg.z01[(dbg_base + b) * S2S_T_DEC + t] = z;
                 const float sd = P.noise_sampling
-                                     ? __fmul_rn(__fmul_rn(fmaxf(sig_ext[q], P.min_noise), P.noise_std), M.scale)
+                                     ? __fmul_rn(__fmul_rn(fmaxf(se, P.min_noise), P.noise_std), M.scale)
                                      : P.noise_std;
                 if (y != 0.0f) y = __fadd_rn(y, __fmul_rn(z, sd));
             }

@@ -30,14 +30,14 @@ def _chunks(k, n_chunks, seed=0):
     return torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda()
 
 
-@pytest.mark.parametrize("conc_bias,rate_bias", [(None, None), (-0.43, -6.0), (-2.0, -6.0)],
+@pytest.mark.parametrize("conc_bias,rate_bias", [(None, None), (-0.43, -6.0), (-2.0, -9.0)],
                          ids=["conc9", "conc0.5", "conc0.13"])
 def test_gamma_dwell_distribution(conc_bias, rate_bias):
     sd, cfg = load_ckpt("k9")
     sd = dict(sd)
     if conc_bias is not None:        # softplus(-0.43) ~ 0.5, softplus(-2) ~ 0.13: Marsaglia-Tsang's alpha < 1 boost
         sd["length_regulator.duration_sampler.conc_layer.3.bias"] = torch.tensor([conc_bias])
-        sd["length_regulator.duration_sampler.rate_layer.3.bias"] = torch.tensor([rate_bias])   # rate ~ 0.0025: few draws below 1
+        sd["length_regulator.duration_sampler.rate_layer.3.bias"] = torch.tensor([rate_bias])   # rate ~ 2.5e-3 / 1.2e-4: under half of the draws fall below the clamp at 1
     eng = S.Engine(sd, cfg, mode="f16x3")
     b, n = _chunks(9, 7000)                                             # 112,000 dwell draws
     out = eng.predict_chunks(b, n, S.PredictParams(min_duration=0.0, noise_std=0.0, seed=11), debug=True)

@@ -22,8 +22,9 @@ for it in range(2):
     _lib.lib().s2s_diag_read(eng._h, out)
 v = list(out)
 names = {0: "entry barrier wait", 1: "K/V GEMM + LDS store", 2: "barrier 2 wait", 3: "attention (Q, S, softmax, PV, fc)",
-         4: "LN1", 5: "FFN", 6: "LN2", 8: "prologue (LR gather)", 9: "epilogue", 15: "blocks total"}
-tot = sum(v[i] for i in (0, 1, 2, 3, 4, 5, 6, 8, 9))
+         4: "LN1 (+ FFN fill issue, operand split)", 5: "FFN", 6: "LN2", 8: "prologue (LR gather)", 9: "epilogue",
+         12: "barrier: attention done (FFN_LDS)", 13: "wait: FFN weights landed", 14: "barrier: weights visible", 15: "blocks total"}
+tot = sum(v[i] for i in (0, 1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 14))
 nw = bases.shape[0] * 8
 for i in sorted(names):
     print(f"{names[i]:40s} {v[i] / nw:12.0f} cycles/wave  {100 * v[i] / tot:5.1f} %")
