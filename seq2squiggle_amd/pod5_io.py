@@ -5,8 +5,10 @@ container below follows the published format description (pod5-file-format: docs
 c++/pod5_format/footer.fbs) from the author's knowledge of it, with pyarrow for the embedded Arrow IPC files and a
 hand-written flatbuffer for the footer.  What IS pinned: the per-read record content (ids, calibration, int16 samples,
 run info) against what the reference's POD5Writer hands to the library (tests/golden/pod5_records.npz), and a round
-trip through the reader in this file.  What is NOT: acceptance by libpod5 / dorado.  Signals are stored uncompressed
-(`large_list<int16>`; the VBZ codec needs zstd, also absent).
+trip through the reader in this file.  What is NOT: acceptance by libpod5 / dorado.  Signal rows are VBZ-compressed as
+libpod5 does it (`large_binary` column with the "minknow.vbz" extension type; codecs.vbz_compress = svb16 zig-zag delta +
+zstd level 1, pinned by known-answer vectors); `signal_compression="none"` (or S2S_POD5_SIGNAL=none) writes the format's
+uncompressed variant (`large_list<int16>`) instead.
 
 Layout:  signature | marker | signal table | pad8 | marker | run-info table | pad8 | marker | reads table | pad8 |
          marker | "FOOTER\\0\\0" | flatbuffer (size multiple of 8) | int64 footer length | marker | signature
@@ -158,18 +160,26 @@ class _SubFile:
         return False
 
 
-def _signal_schema(pa, meta):
-    return pa.schema([_uuid_field(pa), pa.field("signal", pa.large_list(pa.int16())), pa.field("samples", pa.uint32())],
-                     metadata=meta)
+def _signal_schema(pa, meta, vbz=True):
+    if vbz:
+        sig = pa.field("signal", pa.large_binary(), nullable=False,
+                       metadata={"ARROW:extension:name": "minknow.vbz", "ARROW:extension:metadata": ""})
+    else:
+        sig = pa.field("signal", pa.large_list(pa.int16()))
+    return pa.schema([_uuid_field(pa), sig, pa.field("samples", pa.uint32())], metadata=meta)
 
 
-def _signal_batch(pa, schema, rows):
-    """rows: (read_id bytes, int16 array) per signal-table row."""
+def _signal_batch(pa, schema, rows, vbz=True):
+    """rows: (read_id bytes, int16 array [, VBZ bytes already made]) per signal-table row."""
     counts = [len(r[1]) for r in rows]
+    ids = pa.array([r[0] for r in rows], pa.binary(16))
+    if vbz:
+        from .codecs import vbz_compress
+        blobs = [r[2] if len(r) > 2 and r[2] is not None else vbz_compress(r[1]) for r in rows]
+        return pa.record_batch([ids, pa.array(blobs, pa.large_binary()), pa.array(counts, pa.uint32())], schema=schema)
     flat = np.concatenate([r[1] for r in rows]) if rows else np.zeros(0, np.int16)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    return pa.record_batch([pa.array([r[0] for r in rows], pa.binary(16)),
-                            pa.LargeListArray.from_arrays(pa.array(offs, pa.int64()), pa.array(flat, pa.int16())),
+    return pa.record_batch([ids, pa.LargeListArray.from_arrays(pa.array(offs, pa.int64()), pa.array(flat, pa.int16())),
                             pa.array(counts, pa.uint32())], schema=schema)
 
 
@@ -239,8 +249,14 @@ class Pod5FileWriter:
     pore_type, calibration_offset, calibration_scale, end_reason (a name from END_REASONS), end_reason_forced, run_info
     (dict with RUN_INFO_FIELDS; reads may share one)."""
 
-    def __init__(self, path: str, file_identifier: uuid.UUID = None, section_marker: bytes = None):
+    def __init__(self, path: str, file_identifier: uuid.UUID = None, section_marker: bytes = None,
+                 signal_compression: str = None):
+        import os
         pa = self.pa = _pa()
+        signal_compression = signal_compression or os.environ.get("S2S_POD5_SIGNAL", "vbz")
+        if signal_compression not in ("vbz", "none"):
+            raise ValueError("POD5 signal_compression must be 'vbz' or 'none'")
+        self.vbz = signal_compression == "vbz"
         self.file_identifier = file_identifier or uuid.uuid4()
         self.marker = section_marker or uuid.uuid4().bytes
         self.meta = {"MINKNOW:file_identifier": str(self.file_identifier), "MINKNOW:software": SOFTWARE,
@@ -249,7 +265,7 @@ class Pod5FileWriter:
         self.f.write(SIGNATURE + self.marker)
         self.entries = []
         self._sig_start = self.f.tell()
-        self._sig_schema = _signal_schema(pa, self.meta)
+        self._sig_schema = _signal_schema(pa, self.meta, self.vbz)
         self._sig_writer = pa.ipc.new_file(_SubFile(self.f), self._sig_schema)
         self._pending, self._n_rows = [], 0           # signal rows not yet written; rows written + pending
         self._reads, self._rows_of = [], []
@@ -270,7 +286,7 @@ class Pod5FileWriter:
                 self._run_infos.append(r["run_info"])
             self._reads.append({k: v for k, v in r.items() if k != "signal"} | {"num_samples": len(raw)})
         while len(self._pending) >= SIGNAL_BATCH_ROWS:
-            self._sig_writer.write_batch(_signal_batch(self.pa, self._sig_schema, self._pending[:SIGNAL_BATCH_ROWS]))
+            self._sig_writer.write_batch(_signal_batch(self.pa, self._sig_schema, self._pending[:SIGNAL_BATCH_ROWS], self.vbz))
             del self._pending[:SIGNAL_BATCH_ROWS]
 
     def _end_embedded(self, start, content_type):
@@ -284,7 +300,7 @@ class Pod5FileWriter:
         self.closed = True
         pa = self.pa
         if self._pending:
-            self._sig_writer.write_batch(_signal_batch(pa, self._sig_schema, self._pending))
+            self._sig_writer.write_batch(_signal_batch(pa, self._sig_schema, self._pending, self.vbz))
             self._pending = []
         self._sig_writer.close()
         self._end_embedded(self._sig_start, CT_SIGNAL)
@@ -305,15 +321,26 @@ class Pod5FileWriter:
         self.close()
 
 
-def write_pod5(path: str, reads: List[dict], file_identifier: uuid.UUID = None, section_marker: bytes = None) -> None:
-    with Pod5FileWriter(path, file_identifier, section_marker) as w:
+def write_pod5(path: str, reads: List[dict], file_identifier: uuid.UUID = None, section_marker: bytes = None,
+               signal_compression: str = None) -> None:
+    with Pod5FileWriter(path, file_identifier, section_marker, signal_compression) as w:
         w.add_reads(reads)
 
 
 def _signal_rows(sig) -> List[np.ndarray]:
-    """int16 samples of every signal-table row, as numpy views of the Arrow buffers (no Python ints)."""
+    """int16 samples of every signal-table row: VBZ rows decoded, uncompressed rows as numpy views of the Arrow buffers."""
+    pa = _pa()
     rows = []
-    for ch in sig.column("signal").chunks:
+    col, counts = sig.column("signal"), sig.column("samples").to_numpy()
+    if pa.types.is_large_binary(col.type):
+        from .codecs import vbz_decompress
+        i = 0
+        for ch in col.chunks:
+            for v in ch:
+                rows.append(vbz_decompress(v.as_buffer(), int(counts[i])))
+                i += 1
+        return rows
+    for ch in col.chunks:
         offs = ch.offsets.to_numpy()
         vals = ch.values.to_numpy(zero_copy_only=False)
         rows.extend(vals[offs[i]:offs[i + 1]] for i in range(len(ch)))

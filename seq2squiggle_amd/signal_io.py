@@ -8,10 +8,14 @@ v0.2.0) are written natively.  The writer protocol is the reference's: the model
 Deviations from the reference, on purpose:
   * read ids / read_number count over the whole run, not per save() call (the reference restarts
     `idx` at every export batch and so writes duplicate `indexed_uuid`s, signal_io.py:123,145);
-  * BLOW5 records are zlib-compressed with uncompressed int16 signal (pyslow5's default is zlib +
-    svb-zd); both are valid BLOW5, the file is larger.
-  * POD5 goes through the native container writer of pod5_io.py: record content pinned against the reference,
-    container unvalidated against libpod5, samples uncompressed (no zstd here for VBZ).
+  * BLOW5 records are zlib-compressed (pyslow5's default record method) with the int16 signal stored as is (signal method
+    "none" in the file header).  pyslow5's default signal method, svb-zd, and zstd records are available
+    (`signal_compression="svb-zd"`, `record_compression="zstd"`, or S2S_BLOW5_SIGNAL / S2S_BLOW5_RECORD in the environment):
+    the codec itself is pinned by known-answer vectors (codecs.py), but how slow5lib frames the compressed signal inside a
+    record is written from memory of its source (see _blow5_record) and could not be checked against the library, which
+    is why it is opt-in.
+  * POD5 goes through the native container writer of pod5_io.py: record content pinned against the reference, signal rows
+    VBZ-compressed like the pod5 library's (codecs.py), container unvalidated against libpod5.
 """
 import logging
 import os
@@ -80,12 +84,20 @@ def _skip_record_draws(n_reads: int) -> None:
 class BLOW5Writer:
     """Writes `.slow5` (ASCII) or `.blow5` (binary) by the file extension."""
 
-    def __init__(self, filename, profile, ideal_mode, profile_name, preserve_read_ids):
+    RECORD_METHODS = {"none": 0, "zlib": 1, "zstd": 2}     # on-disk codes (slow5lib slow5_encode_record_press)
+    SIGNAL_METHODS = {"none": 0, "svb-zd": 1}              # (slow5_encode_signal_press)
+
+    def __init__(self, filename, profile, ideal_mode, profile_name, preserve_read_ids, record_compression=None,
+                 signal_compression=None):
         self.filename = str(filename)
         self.profile = profile
         self.ideal_mode = ideal_mode
         self.profile_name = profile_name
         self.preserve_read_ids = preserve_read_ids
+        self.record_compression = record_compression or os.environ.get("S2S_BLOW5_RECORD", "zlib")
+        self.signal_compression = signal_compression or os.environ.get("S2S_BLOW5_SIGNAL", "none")
+        if self.record_compression not in self.RECORD_METHODS or self.signal_compression not in self.SIGNAL_METHODS:
+            raise ValueError(f"BLOW5 compression must be one of {sorted(self.RECORD_METHODS)} x {sorted(self.SIGNAL_METHODS)}")
         self.signals = None
         self.dac = None                       # optional {read_id: int16 array} computed on the GPU
         self.median_before = float(profile["median_before_mean"])
@@ -206,14 +218,30 @@ class BLOW5Writer:
     _EOF = b"5WOLB"
 
     def _blow5_record(self, r) -> bytes:
+        """u64 size + the (record-compressed) body.  Body: read_id_len u16, read_id, read_group u32, digitisation, offset,
+        range, sampling_rate f64, len_raw_signal u64, raw_signal, then the auxiliary fields in header order.
+        With signal method svb-zd the raw_signal bytes are the codec's blob (u32 sample count + StreamVByte stream) and --
+        as remembered from slow5lib's slow5_rec_to_mem / slow5_rec_parse, NOT verified against the library -- the
+        len_raw_signal field then carries the blob's byte length (the parser needs it to find the auxiliary fields; the
+        sample count is inside the blob)."""
         rid, ch = r["read_id"].encode(), r["channel_number"].encode()
+        raw = np.ascontiguousarray(r["signal"]).astype("<i2")
+        if self.signal_compression == "svb-zd":
+            from .codecs import svb_zd_compress
+            sig = r.get("svb") or svb_zd_compress(raw)
+            n_field = len(sig)
+        else:
+            sig, n_field = raw.tobytes(), r["len_raw_signal"]
         body = (struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", r["read_group"], r["digitisation"], r["offset"],
-                                                                 r["range"], r["sampling_rate"], r["len_raw_signal"])
-                + np.ascontiguousarray(r["signal"]).astype("<i2").tobytes()
-                + struct.pack("<H", len(ch)) + ch
+                                                                 r["range"], r["sampling_rate"], n_field)
+                + sig + struct.pack("<H", len(ch)) + ch
                 + struct.pack("<diBQ", r["median_before"], r["read_number"], r["start_mux"], r["start_time"]))
-        z = zlib.compress(body, self.compress_level)
-        return struct.pack("<Q", len(z)) + z
+        if self.record_compression == "zlib":
+            body = zlib.compress(body, self.compress_level)
+        elif self.record_compression == "zstd":
+            from .codecs import zstd_compress
+            body = zstd_compress(body, 1)
+        return struct.pack("<Q", len(body)) + body
 
     def _save_blow5(self, append: bool, recs):
         if append:
@@ -225,7 +253,8 @@ class BLOW5Writer:
         with open(self.filename, "ab" if append else "wb") as f:
             if not append:
                 hdr = self._header_text().encode()
-                fh = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1]) + struct.pack("<I", 1) + bytes([0])
+                fh = (b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([self.RECORD_METHODS[self.record_compression]])
+                      + struct.pack("<I", 1) + bytes([self.SIGNAL_METHODS[self.signal_compression]]))
                 f.write(fh + bytes(64 - len(fh)))
                 f.write(struct.pack("<I", len(hdr)) + hdr)
             # zlib releases the GIL: compress records on worker threads, write in order
@@ -240,21 +269,33 @@ class BLOW5Writer:
 
 def read_blow5(path):
     """Minimal reader of the files written above (tests / round-trip only)."""
+    from . import codecs
     with open(path, "rb") as f:
         data = f.read()
     assert data[:6] == b"BLOW5\x01" and data[-5:] == BLOW5Writer._EOF
+    rec_m, sig_m = data[9], data[14]
     hlen = struct.unpack_from("<I", data, 64)[0]
     header = data[68:68 + hlen].decode()
     pos, recs = 68 + hlen, []
     while pos < len(data) - 5:
         n = struct.unpack_from("<Q", data, pos)[0]
-        body = zlib.decompress(data[pos + 8:pos + 8 + n])
+        body = data[pos + 8:pos + 8 + n]
+        if rec_m == 1:
+            body = zlib.decompress(body)
+        elif rec_m == 2:
+            body = codecs.zstd_decompress(body, codecs.zstd_frame_content_size(body))
         pos += 8 + n
         o = 0
         (ln,) = struct.unpack_from("<H", body, o); o += 2
         rid = body[o:o + ln].decode(); o += ln
         rg, dig, off, rng, sr, nsig = struct.unpack_from("<IddddQ", body, o); o += struct.calcsize("<IddddQ")
-        sig = np.frombuffer(body, dtype="<i2", count=nsig, offset=o); o += 2 * nsig
+        if sig_m == 1:
+            sig, used = codecs.svb_zd_decompress(body[o:o + nsig])
+            assert used == nsig
+            o += nsig
+            nsig = len(sig)
+        else:
+            sig = np.frombuffer(body, dtype="<i2", count=nsig, offset=o); o += 2 * nsig
         (cl,) = struct.unpack_from("<H", body, o); o += 2
         ch = body[o:o + cl].decode(); o += cl
         mb, rn, mux, st_ = struct.unpack_from("<diBQ", body, o)
@@ -359,6 +400,8 @@ class POD5Writer:
             logger.warning("POD5 was not exported. No signals were found")
             raise ValueError("POD5 was not exported. No signals were found")
         from . import pod5_io
+        logger.warning("POD5 output comes from seq2squiggle_amd's own container writer (unvalidated against ONT's pod5 "
+                       "library, which this image lacks).")
         pod5_io.write_pod5(self.filename, self.records())
 
     # ---- streaming path (inference.run_streaming): samples already int16 on the GPU, reads arrive in super-batches and
@@ -377,6 +420,9 @@ class POD5Writer:
     def write_records(self, recs) -> None:
         if self._stream is None:
             from . import pod5_io
+            logger.warning("POD5 output comes from seq2squiggle_amd's own container writer: record content and the VBZ codec "
+                           "are pinned against the reference / known-answer vectors, but no file has been opened with ONT's "
+                           "pod5 library yet (absent from this image). Prefer .blow5 where the consumer allows it.")
             self._stream = pod5_io.Pod5FileWriter(self.filename)
         self._stream.add_reads(recs)
 

@@ -107,7 +107,8 @@ def test_pod5_records_match_reference_writer(tmp_path, case):
     assert set(ri) == set(pod5_io.RUN_INFO_FIELDS)
 
 
-def test_pod5_container_layout(tmp_path):
+@pytest.mark.parametrize("compression", ["vbz", "none"])
+def test_pod5_container_layout(tmp_path, compression):
     """Signature, section markers, 8-byte padding, footer magic/length, flatbuffer footer (parsed by hand here, field by
     field, independently of pod5_io.parse_footer) and the embedded Arrow files' schema metadata."""
     import io, struct, uuid, datetime
@@ -124,7 +125,7 @@ def test_pod5_container_layout(tmp_path):
              for i, n in enumerate(lens)]
     path = str(tmp_path / "c.pod5")
     marker, ident = bytes(range(16)), uuid.UUID(int=7)
-    P.write_pod5(path, reads, file_identifier=ident, section_marker=marker)
+    P.write_pod5(path, reads, file_identifier=ident, section_marker=marker, signal_compression=compression)
     data = open(path, "rb").read()
     assert data[:8] == data[-8:] == b"\x8bPOD\r\n\x1a\n" and data[8:24] == data[-24:-8] == marker
     flen = struct.unpack_from("<q", data, len(data) - 32)[0]
@@ -159,13 +160,56 @@ def test_pod5_container_layout(tmp_path):
     sig = pa.ipc.open_file(io.BytesIO(data[seen[P.CT_SIGNAL][0]: sum(seen[P.CT_SIGNAL])]))
     assert sig.schema.metadata[b"MINKNOW:pod5_version"] == P.POD5_VERSION.encode()
     assert sig.schema.field("read_id").metadata[b"ARROW:extension:name"] == b"minknow.uuid"
-    assert sig.schema.field("signal").type == pa.large_list(pa.int16())
+    if compression == "vbz":          # libpod5's compressed signal column: large_binary tagged minknow.vbz, one zstd frame per row
+        assert sig.schema.field("signal").type == pa.large_binary()
+        assert sig.schema.field("signal").metadata[b"ARROW:extension:name"] == b"minknow.vbz"
+        first = sig.get_batch(0)
+        blob, n = first.column(1)[1].as_py(), first.column(2)[1].as_py()          # row 1 = first row of the long read
+        assert blob[:4] == b"\x28\xb5\x2f\xfd" and n == P.SIGNAL_CHUNK
+        from seq2squiggle_amd import codecs
+        assert np.array_equal(codecs.vbz_decompress(blob, n), reads[1]["signal"][:n])
+    else:
+        assert sig.schema.field("signal").type == pa.large_list(pa.int16())
     sizes = [sig.get_batch(i).num_rows for i in range(sig.num_record_batches)]
     assert all(n == P.SIGNAL_BATCH_ROWS for n in sizes[:-1]) and sum(sizes) == len(lens) + 2
     d = P.read_pod5(path)
     assert [len(r["signal"]) for r in d["reads"]] == lens and d["reads"][1]["signal"].tolist() == reads[1]["signal"].tolist()
     assert d["reads"][1]["signal"].dtype == np.int16 and len(reads_rows := d["reads"][1]) and d["signal_rows"] == len(lens) + 2
     assert d["run_info"][0]["acquisition_start_time"].year == 2024 and d["run_info"][0]["context_tags"] == [("k", "v")]
+
+
+@pytest.mark.parametrize("rec", ["none", "zlib", "zstd"])
+@pytest.mark.parametrize("sig", ["none", "svb-zd"])
+def test_blow5_compression_methods(tmp_path, rec, sig):
+    """Header method bytes (slow5lib's on-disk codes: record none/zlib/zstd = 0/1/2, signal none/svb-zd = 0/1), record
+    framing, and for svb-zd the blob of codecs.svb_zd_compress in place of the raw samples."""
+    import struct, zlib
+    from seq2squiggle_amd import codecs
+    w = signal_io.BLOW5Writer(str(tmp_path / "c.blow5"), U.get_profile("dna-r10-prom"), True, "dna-r10-prom", True,
+                              record_compression=rec, signal_compression=sig)
+    sigs = [np.array([100, 102, 99, 400, -5], np.int16), np.cumsum(np.random.default_rng(0).integers(-30, 31, 3000)).astype(np.int16)]
+    offs = np.array([0, 5, 3005])
+    w.save_dac(["a", "b"], np.concatenate(sigs), offs)
+    data = open(w.filename, "rb").read()
+    assert data[:9] == b"BLOW5\x01\x00\x02\x00" and data[9] == {"none": 0, "zlib": 1, "zstd": 2}[rec]
+    assert struct.unpack_from("<I", data, 10)[0] == 1 and data[14] == {"none": 0, "svb-zd": 1}[sig] and not any(data[15:64])
+    pos = 68 + struct.unpack_from("<I", data, 64)[0]
+    n = struct.unpack_from("<Q", data, pos)[0]
+    body = data[pos + 8: pos + 8 + n]
+    body = zlib.decompress(body) if rec == "zlib" else codecs.zstd_decompress(body, codecs.zstd_frame_content_size(body)) \
+        if rec == "zstd" else body
+    assert body[:3] == b"\x01\x00a"
+    field = struct.unpack_from("<Q", body, 3 + 4 + 32)[0]
+    blob = body[3 + 4 + 32 + 8:]
+    if sig == "svb-zd":      # the hand-computed vector of tests/golden/codec_kat.json
+        assert field == 13 and blob[:13].hex() == "050000004001c804055a022903"
+    else:
+        assert field == 5 and blob[:10] == sigs[0].astype("<i2").tobytes()
+    _, recs = signal_io.read_blow5(w.filename)
+    assert [r["read_id"] for r in recs] == ["a", "b"] and all(np.array_equal(r["signal"], x) for r, x in zip(recs, sigs))
+    with pytest.raises(ValueError):
+        signal_io.BLOW5Writer(str(tmp_path / "d.blow5"), U.get_profile("dna-r10-prom"), True, "dna-r10-prom", True,
+                              record_compression="lzma")
 
 
 def test_onehot_to_bases_equals_chunker():
