@@ -163,6 +163,27 @@ int s2s_export_reads(s2s_handle* h, void* stream, const float* signal, int32_t B
                      int16_t* out_dac, int64_t capacity, float digitisation, float range,
                      float offset_mean, int32_t rna);
 
+/* Replaces the signal compression that pyslow5.write_record_batch (svb-zd) and pod5.Writer.add_reads (the svb16 stage of
+ * VBZ) run on the host (reference signal_io.py:167-171, 268-282): StreamVByte encoding of the zig-zag deltas of the packed
+ * int16 samples, one output blob per row, so that only ~1.1 bytes per sample cross PCIe.
+ *
+ *  samples       device int16: out_dac of s2s_export_reads;
+ *  read_offsets  device [R+1]: out_offsets of s2s_export_reads;
+ *  row_read, row_index  device [N]: row i covers samples [row_index[i]*row_samples, (row_index[i]+1)*row_samples) of read
+ *               row_read[i], clipped to the read; a row that starts past the end of its read yields an empty blob (the
+ *               caller enumerates candidate rows from the chunk counts without knowing the stripped lengths);
+ *  row_samples   samples per row: 102400 for POD5 signal-table rows, any value >= the longest read for whole reads (SLOW5);
+ *  variant       32: slow5 svb-zd blob = u32 n, (n+3)/4 control bytes (2 bits per value), data (zig-zag of 32-bit deltas);
+ *               16: pod5 svb16 stream = (n+7)/8 control bytes (1 bit per value), data (zig-zag of 16-bit deltas): the
+ *               input of the row's zstd frame;
+ *  out           device bytes [capacity]; capacity >= N*4 + total_samples*3 + N (variant 32) or total_samples*2 + N + total/8
+ *               (variant 16) always suffices;
+ *  out_offsets   device [N+1] int64: blob i = out[out_offsets[i] : out_offsets[i+1]].
+ */
+int s2s_svb_encode(s2s_handle* h, void* stream, const int16_t* samples, const int64_t* read_offsets,
+                   const int32_t* row_read, const int32_t* row_index, int32_t N, int64_t row_samples, int32_t variant,
+                   uint8_t* out, int64_t capacity, int64_t* out_offsets);
+
 /* Test hook: raw Philox4x32-10 words, out[i*4..i*4+3] = philox(counter = {c0+i, c1, c2, c3}, key = seed). */
 int s2s_philox_u32(s2s_handle* h, void* stream, uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
                    uint32_t c3, int32_t n, uint32_t* out /* device [n][4] */);

@@ -25,7 +25,7 @@ class S2SDebug(C.Structure):
 
 
 EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
-           "s2s_export_reads", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read")
+           "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read")
 
 
 def lib():
@@ -54,6 +54,8 @@ def lib():
     L.s2s_predict_packed.argtypes = [vp, vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp]
     L.s2s_export_reads.restype = i32
     L.s2s_export_reads.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i64, f32, f32, f32, i32]
+    L.s2s_svb_encode.restype = i32
+    L.s2s_svb_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp]
     L.s2s_philox_u32.restype = i32
     L.s2s_philox_u32.argtypes = [vp, vp, u64, u32, u32, u32, u32, i32, vp]
     L.s2s_set_profiling.restype = i32

@@ -367,6 +367,93 @@ __global__ __launch_bounds__(256) void s2s_compact_kernel(const float* __restric
     }
 }
 
+// ---- StreamVByte encoders of the output containers (codecs.py states the formats): one 256-thread workgroup per row.
+// VARIANT 32 (slow5 svb-zd): [u32 n][(n+3)/4 control bytes, 2 bits per value][data: 1..4 bytes per value] of the zig-zag
+// deltas widened to 32 bits; VARIANT 16 (pod5 VBZ before zstd): [(n+7)/8 control bytes, 1 bit per value][1..2 bytes per value]
+// of the zig-zag deltas in 16-bit arithmetic.  A thread owns 8 consecutive values = one (svb16) or two (svb32) control bytes;
+// their data bytes are placed by a block-wide prefix sum with a running carry.  WRITE = false only sizes the row.
+template <int VARIANT, bool WRITE>
+__global__ __launch_bounds__(256) void s2s_svb_kernel(const short* __restrict__ samples, const long long* __restrict__ read_offs,
+                                                      const int* __restrict__ row_read, const int* __restrict__ row_index,
+                                                      long long row_samples, int* __restrict__ row_bytes,
+                                                      const long long* __restrict__ out_offs, unsigned char* __restrict__ out,
+                                                      long long capacity) {
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rd = row_read[row];
+    const long long r0 = read_offs[rd], rn = read_offs[rd + 1] - r0;
+    const long long lo = (long long)row_index[row] * row_samples;
+    long long n = rn - lo;
+    if (n > row_samples) n = row_samples;
+    if (n <= 0) {                                            // a candidate row the read turned out not to need
+        if (!WRITE && tid == 0) row_bytes[row] = 0;
+        return;
+    }
+    const short* x = samples + r0 + lo;
+    const long long nkeys = (VARIANT == 32) ? (n + 3) / 4 : (n + 7) / 8;
+    const int hdr = (VARIANT == 32) ? 4 : 0;
+    unsigned char* o = nullptr;
+    if (WRITE) {
+        const long long base = out_offs[row];
+        if (out_offs[row + 1] > capacity) return;            // (the host sized the buffer for the worst case: cannot happen)
+        o = out + base;
+        if (VARIANT == 32 && tid == 0) { const unsigned nn = (unsigned)n; o[0] = nn; o[1] = nn >> 8; o[2] = nn >> 16; o[3] = nn >> 24; }
+    }
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (long long t0 = 0; t0 < n; t0 += 2048) {
+        const long long j0 = t0 + 8 * (long long)tid;
+        unsigned v[8];
+        int len[8], tot = 0;
+        unsigned key = 0;
+        int prev = (j0 > 0 && j0 <= n) ? x[j0 - 1] : 0;       // (the delta of a row's first value is against 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            len[i] = 0; v[i] = 0;
+            if (j0 + i < n) {
+                const int cur = x[j0 + i];
+                if (VARIANT == 32) {
+                    const int d = cur - prev;
+                    v[i] = ((unsigned)d << 1) ^ (unsigned)(d >> 31);
+                    len[i] = 1 + (v[i] > 0xFFu) + (v[i] > 0xFFFFu) + (v[i] > 0xFFFFFFu);
+                    key |= (unsigned)(len[i] - 1) << (2 * i);
+                } else {
+                    const short d = (short)((unsigned short)cur - (unsigned short)prev);
+                    v[i] = (unsigned short)(((int)d + (int)d) ^ ((int)d >> 15));
+                    len[i] = 1 + (v[i] > 0xFFu);
+                    key |= (unsigned)(len[i] - 1) << i;
+                }
+                prev = cur;
+                tot += len[i];
+            }
+        }
+        int incl = tot;                                       // block-wide exclusive prefix of `tot`
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int pre = carry_s + incl - tot;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (WRITE && j0 < n) {
+            if (VARIANT == 32) {
+                o[hdr + j0 / 4] = (unsigned char)key;
+                if (j0 + 4 < n) o[hdr + j0 / 4 + 1] = (unsigned char)(key >> 8);
+            } else {
+                o[j0 / 8] = (unsigned char)key;
+            }
+            unsigned char* d = o + hdr + nkeys + pre;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                for (int k = 0; k < len[i]; ++k) *d++ = (unsigned char)(v[i] >> (8 * k));
+        }
+        __syncthreads();
+        if (tid == 255) carry_s = pre + tot;
+        __syncthreads();
+    }
+    if (!WRITE && tid == 0) row_bytes[row] = (int)(hdr + nkeys + carry_s);
+}
+
 __global__ void s2s_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned c0, unsigned c1, unsigned c2, unsigned c3,
                                   int n, unsigned* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -397,6 +484,8 @@ struct s2s_handle {
     int* ws_counts = nullptr;         // export scratch, grown on demand outside of launches
     long long* ws_offs = nullptr;
     int ws_export_cap = 0;
+    int* ws_svb = nullptr;            // s2s_svb_encode scratch: bytes per row
+    int ws_svb_cap = 0;
     bool profiling = false;
     unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: 16 per-phase wave-cycle sums
     std::vector<EventPair> events;
@@ -714,6 +803,7 @@ void s2s_destroy(s2s_handle* h) {
     if (h->ws_sigma) (void)hipFree(h->ws_sigma);
     if (h->ws_counts) (void)hipFree(h->ws_counts);
     if (h->ws_offs) (void)hipFree(h->ws_offs);
+    if (h->ws_svb) (void)hipFree(h->ws_svb);
     if (h->d_diag) (void)hipFree(h->d_diag);
     delete h;
 }
@@ -825,6 +915,48 @@ int s2s_export_reads(s2s_handle* h, void* stream_, const float* signal, int32_t 
         hipLaunchKernelGGL(s2s_compact_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, signal, B, h->ws_offs, read_first, R,
                            out_pa, reinterpret_cast<short*>(out_dac), (long long)capacity, digitisation, range, offset_mean,
                            rna);
+    HIP_TRY(h, hipGetLastError());
+    return S2S_OK;
+}
+
+int s2s_svb_encode(s2s_handle* h, void* stream_, const int16_t* samples, const int64_t* read_offsets, const int32_t* row_read,
+                   const int32_t* row_index, int32_t N, int64_t row_samples, int32_t variant, uint8_t* out, int64_t capacity,
+                   int64_t* out_offsets) {
+    if (!h) return S2S_ERR_ARG;
+    if (N < 0 || row_samples <= 0 || (variant != 16 && variant != 32)) return fail(h, S2S_ERR_ARG, "bad argument");
+    if (!out_offsets || (N > 0 && (!samples || !read_offsets || !row_read || !row_index || !out)))
+        return fail(h, S2S_ERR_ARG, "NULL argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, S2S_ERR_HIP, "hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N + 1 > h->ws_svb_cap) {             // grows outside of the steady state only
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        if (h->ws_svb) (void)hipFree(h->ws_svb);
+        h->ws_svb = nullptr; h->ws_svb_cap = 0;
+        const int cap = N + 1 + N / 4;
+        HIP_TRY(h, hipMalloc(&h->ws_svb, (size_t)cap * sizeof(int)));
+        h->ws_svb_cap = cap;
+    }
+    const short* sp = reinterpret_cast<const short*>(samples);
+    const long long* ro = reinterpret_cast<const long long*>(read_offsets);
+    long long* oo = reinterpret_cast<long long*>(out_offsets);
+    if (N > 0) {
+        if (variant == 32)
+            hipLaunchKernelGGL((s2s_svb_kernel<32, false>), dim3(N), dim3(256), 0, stream, sp, ro, row_read, row_index,
+                               (long long)row_samples, h->ws_svb, nullptr, nullptr, 0LL);
+        else
+            hipLaunchKernelGGL((s2s_svb_kernel<16, false>), dim3(N), dim3(256), 0, stream, sp, ro, row_read, row_index,
+                               (long long)row_samples, h->ws_svb, nullptr, nullptr, 0LL);
+    }
+    hipLaunchKernelGGL(s2s_scan_kernel, dim3(1), dim3(1024), 0, stream, h->ws_svb, N, oo);
+    if (N > 0) {
+        if (variant == 32)
+            hipLaunchKernelGGL((s2s_svb_kernel<32, true>), dim3(N), dim3(256), 0, stream, sp, ro, row_read, row_index,
+                               (long long)row_samples, nullptr, oo, out, (long long)capacity);
+        else
+            hipLaunchKernelGGL((s2s_svb_kernel<16, true>), dim3(N), dim3(256), 0, stream, sp, ro, row_read, row_index,
+                               (long long)row_samples, nullptr, oo, out, (long long)capacity);
+    }
     HIP_TRY(h, hipGetLastError());
     return S2S_OK;
 }

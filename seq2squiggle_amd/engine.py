@@ -174,6 +174,26 @@ class Engine:
         self._check(rc, "s2s_export_reads")
         return {"offsets": offs, "pa": pa, "dac": dac}
 
+    def svb_encode(self, dac: torch.Tensor, read_offsets: torch.Tensor, row_read: torch.Tensor, row_index: torch.Tensor,
+                   row_samples: int, variant: int, total_samples_bound: int):
+        """StreamVByte blobs of the rows (see s2s_svb_encode in include/s2s_hip.h) -> dict(out uint8 [capacity],
+        offsets int64 [N+1]) on the device.  total_samples_bound: an upper bound of the samples the rows hold together."""
+        N = int(row_read.shape[0])
+        for name, t, dt in (("dac", dac, torch.int16), ("read_offsets", read_offsets, torch.int64),
+                            ("row_read", row_read, torch.int32), ("row_index", row_index, torch.int32)):
+            if t.dtype != dt or t.dim() != 1 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{name} must be a contiguous 1-D {dt} tensor on {self.device}")
+        if row_index.shape[0] != N or variant not in (16, 32):
+            raise ValueError("row_read / row_index differ in length, or variant is not 16 | 32")
+        cap = (3 * total_samples_bound + 5 * N) if variant == 32 else (2 * total_samples_bound + total_samples_bound // 8 + N)
+        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=self.device)
+        offs = torch.empty(N + 1, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().s2s_svb_encode(self._h, self._stream(), _ptr(dac), _ptr(read_offsets), _ptr(row_read),
+                                           _ptr(row_index), N, int(row_samples), int(variant), _ptr(out), cap, _ptr(offs))
+        self._check(rc, "s2s_svb_encode")
+        return {"out": out, "offsets": offs}
+
     # ------------------------------------------------------------------ misc
     def philox_u32(self, seed: int, c0: int, c1: int, c2: int, c3: int, n: int) -> torch.Tensor:
         out = torch.empty(n, 4, dtype=torch.int32, device=self.device)

@@ -77,6 +77,20 @@ def iter_batches(reads: Iterable[Tuple[str, str]], k: int, batch_size: int, devi
         yield tuple(ids), torch.from_numpy(np.concatenate(parts)).to(device), torch.from_numpy(np.concatenate(nvs)).to(device)
 
 
+_IO = None
+
+
+def _io_executor():
+    """ONE writer thread for the whole process.  (Not one per run: with the pyarrow build of this image, Arrow calls from
+    a second thread after a first Arrow-using thread has exited segfault, so the container writers always run on this
+    long-lived thread.)"""
+    global _IO
+    if _IO is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _IO = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-writer")
+    return _IO
+
+
 def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
                   max_chunks: int = 32768) -> int:
     """The predict loop without per-chunk Python objects: whole reads are grouped into super-batches of about
@@ -87,12 +101,11 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     Three stages overlap: while the GPU works on super-batch i the host samples/packs i+1, and a writer thread
     compresses and writes i-1.  Record metadata (the np.random offset draws of signal_io.py:129-132) is built on the
     calling thread in read order, so the output does not depend on thread timing."""
-    from concurrent.futures import ThreadPoolExecutor
     k = model.config["seq_kmer"]
     dev = model.device
     rna = profile_name.startswith("rna")
     total = 0
-    io = ThreadPoolExecutor(max_workers=1)
+    io = _io_executor()
     pending = None            # the writer job of the previous super-batch
     inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
     copy_stream = torch.cuda.Stream(dev)
@@ -164,9 +177,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         if pending is not None:
             pending.result()
     finally:
-        io.shutdown(wait=True)
-        if hasattr(writer, "close"):               # POD5: run-info and reads tables, footer
-            writer.close()
+        if hasattr(writer, "close"):               # POD5: run-info and reads tables, footer (on the writer thread as well)
+            io.submit(writer.close).result()
     return total
 
 
