@@ -194,9 +194,10 @@ int s2s_set_profiling(s2s_handle* h, int32_t enabled);
 int s2s_get_kernel_ms(s2s_handle* h, double* decoder_ms_total, int64_t* decoder_launches,
                       int64_t* decoder_chunks);
 
-/* Diagnostic builds (-DS2S_DIAG, never the shipped library): per-phase wave-cycle sums of the
- * decoder kernel since the last call; S2S_ERR_ARG in a normal build. */
-int s2s_diag_read(s2s_handle* h, uint64_t* out16);
+/* Diagnostic builds (-DS2S_DIAG, never the shipped library): 48 per-phase wave-cycle sums since the
+ * last call (0-15 decoder, 16-31 the encoder blocks of the frontend, 32-47 the frontend's own
+ * phases; tools/diag_phases.py names them); S2S_ERR_ARG in a normal build. */
+int s2s_diag_read(s2s_handle* h, uint64_t* out48);
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,14 @@ __device__ float standard_gamma(float alpha, unsigned chunk_lo, unsigned chunk_h
     return scale * d * v;
 }
 
+// a * b + c with the product rounded before the sum, as torch evaluates `z * std + mean` (two kernels).  The __f*_rn
+// intrinsics are plain operators once inlined and hipcc's default -ffp-contract=fast fuses them into one v_fma.
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
+
 __device__ __forceinline__ float softplus_t(float x) {      // nn.Softplus(beta=1, threshold=20)
     return x > 20.0f ? x : log1pf(expf(x));
 }
@@ -212,6 +220,19 @@ __device__ __forceinline__ void layer_norm64(f32x4 (&x)[NQ][4], const float* __r
     layer_norm64_r<NQ>(x, gm, bt);
 }
 
+// Barrier between the phases of a block that exchange K/V through LDS.  SOLO: the block's sequence is one time tile owned
+// by ONE wave (the encoder), so the exchange stays inside the wave -- LDS executes a wave's accesses in issue order, only the
+// compiler has to keep them in program order -- and the block may run in some waves of a larger workgroup and not in others.
+template <bool SOLO>
+__device__ __forceinline__ void block_sync() {
+    if constexpr (SOLO) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 // One weight "unit" = 4 A fragments (4 KiB) = what one 16-row m-tile of a K=64 GEMM consumes.
 // A layer's units are stored in the order the block consumes them (host: pack_layer), so the
 // stream pointer just advances and the next unit is always requested one unit ahead of its use.
@@ -250,7 +271,7 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
     f32x4 fa[4], fb[4];                               // ping-pong unit buffers
 
     load_unit(fa, ws); ws += 1024;                    // Wk, pair 0
-    __syncthreads();
+    block_sync<NKT == 1>();
     DIAG_STAMP(0);                                  // every wave is done reading the previous block's K/V
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS (layers.py:74-78)
 #pragma unroll 1
@@ -290,7 +311,7 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
     DIAG_STAMP(1);
-    if (!(S2S_ABL & 4)) __syncthreads();   // K/V of every wave visible
+    if (!(S2S_ABL & 4)) block_sync<NKT == 1>();   // K/V of every wave visible
     DIAG_STAMP(2);
 
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)

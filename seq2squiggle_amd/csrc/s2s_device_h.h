@@ -111,19 +111,23 @@ __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h
 
 // LDS of the f16 block: K [head][hi|lo][key][8 d] halves, V^T [head][16 rows: 0-7 hi d, 8-15 lo d][VS keys]
 // halves, and a per-wave scratch for the Q^T operand re-layout.
-template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
+// SEP (the encoder in the fused kernel): the wave's NQ time tiles are NQ independent 16-position sequences (one chunk each),
+// every one with its own K/V image of 16 keys; NKT = 1, WAVES = 1 describe one of them.
+template <int NQ, int WAVES, int NKT = 16, bool SEP = false> struct AttnLdsH {
     static constexpr int KEYS = 16 * NKT;
     static constexpr int K_BYTES = 8 * 2 * KEYS * 8 * 2;
     // halves per V^T row.  NKT even (the decoder): a row is stored as [32-key block][lane group g][8 halves] -- the 4 keys 4g..4g+3 of
     // the block's first tile, then those of its second -- so the P.V operand of a K = 32 block is ONE ds_read_b128 per lane;
     // 272 halves = 136 dwords == 8 (mod 64) makes the 16 lanes of every b128 lane group hit 16 distinct 4-dword bank slots.
     // (The natural key order needed two b64 reads, which hipcc fuses into ds_read2_b64: banked mod 32, 2-way conflicts on
-    // every access -- the 11,264 SQ_LDS_BANK_CONFLICT cycles per chunk of profiles/r01.)  NKT = 1 (encoder): natural order.
+    // every access -- the 11,264 SQ_LDS_BANK_CONFLICT cycles per chunk of profiles/r01.)  NKT = 1 (encoder): natural order
+    // (SEP: unpadded rows, so that the 16 sequences of a workgroup fit beside each other).
     static constexpr bool V128 = (NKT % 2) == 0;
-    static constexpr int VS = V128 ? KEYS + 16 : KEYS + 8;
+    static constexpr int VS = V128 ? KEYS + 16 : (SEP ? KEYS : KEYS + 8);
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
+    static constexpr int SEQ_HALVES = (K_BYTES + V_BYTES) / 2;          // one sequence's K and V images
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
-    static constexpr int BYTES = K_BYTES + V_BYTES + WAVES * Q_WAVE_BYTES;
+    static constexpr int BYTES = (SEP ? NQ : 1) * (K_BYTES + V_BYTES) + WAVES * Q_WAVE_BYTES;
 };
 
 // acc[q] += W_unit * x[q]: one 16-row m-tile, K = 64 as two k-blocks, three products each.
@@ -163,17 +167,21 @@ __device__ __forceinline__ void mm_unit_h_t(f32x4 (&acc)[NQ], const f32x4 (&f)[4
     }
 }
 
-// y = W x + b for a 64x64 Linear stored as 4 f16 units (one per 16-row m-tile), single time tile.
+// y = W x + b for a 64x64 Linear stored as 4 f16 units (one per 16-row m-tile), NQ time tiles.
+template <int NQ>
 __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const float* __restrict__ bias, int lane,
-                                           const HL (&xb)[1][2], f32x4 (&y)[1][4]) {
+                                           const HL (&xb)[NQ][2], f32x4 (&y)[NQ][4]) {
     const int g = lane >> 4;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        f32x4 f[4], t[1];
+        f32x4 f[4], t[NQ];
         load_unit(f, wu + mt * 1024 + lane * 4);
-        t[0] = f32x4{0, 0, 0, 0};
-        mm_unit_h<1>(t, f, xb);
-        y[0][mt] = t[0] + ldg4(bias + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
+        mm_unit_h<NQ>(t, f, xb);
+        const f32x4 b = ldg4(bias + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q][mt] = t[q] + b;
     }
 }
 
@@ -184,11 +192,13 @@ __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const f
 //     shift-invariant, so this is exact as long as no later score beats m by the f16 range of P_hi; if one does, the
 //     row sum turns inf/NaN, which the caller checks once per head, and then runs
 //   SAFE = true (rare): a textbook online softmax, the running max raised and the sums rescaled in every pass.
-template <int NQ, int NKT, int TV, bool SAFE, bool LO = true>
+template <int NQ, int NKT, int TV, bool SAFE, bool LO = true, bool SEP = false>
 __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, const _Float16* __restrict__ vp, const h8 (&qb)[NQ],
                                            const h8 ones, const float one, const int g, f32x4 (&oH)[NQ], f32x4 (&oL)[NQ],
                                            f32x4 (&lH)[NQ], f32x4 (&lL)[NQ]) {
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;
+    constexpr int NS = SEP ? NQ : 1;                   // K/V images: one for all tiles, or one per tile (SEP)
+    constexpr int SEQ = AttnLdsH<NQ, 1, NKT, SEP>::SEQ_HALVES;
     f32x4 negm[NQ];
     float m[NQ];
 #pragma unroll
@@ -200,18 +210,21 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
     }
 #pragma unroll
     for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
-        h8 ka[HK], va[HB];
+        h8 ka[NS][HK], va[NS][HB];
 #pragma unroll
-        for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
+        for (int sq = 0; sq < NS; ++sq) {
 #pragma unroll
-        for (int kb = 0; kb < HB; ++kb) {
-            if (AttnLdsH<NQ, 1, NKT>::V128) {              // (vp already points at this lane group's 8 halves of block 0)
-                va[kb] = *reinterpret_cast<const h8*>(vp + 32 * (h2 * HB + kb));
-            } else {
-                const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
-                h4 v1 = h4{0, 0, 0, 0};                    // a K = 32 block past the last key tile: zero keys
-                if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
-                va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            for (int kt = 0; kt < HK; ++kt) ka[sq][kt] = *reinterpret_cast<const h8*>(kp + sq * SEQ + 16 * (h2 * HK + kt) * 8);
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) {
+                if (AttnLdsH<NQ, 1, NKT, SEP>::V128) {    // (vp already points at this lane group's 8 halves of block 0)
+                    va[sq][kb] = *reinterpret_cast<const h8*>(vp + sq * SEQ + 32 * (h2 * HB + kb));
+                } else {
+                    const h4 v0 = *reinterpret_cast<const h4*>(vp + sq * SEQ + 16 * (h2 * HK + 2 * kb));
+                    h4 v1 = h4{0, 0, 0, 0};                // a K = 32 block past the last key tile: zero keys
+                    if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + sq * SEQ + 16 * (h2 * HK + 2 * kb + 1));
+                    va[sq][kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
             }
         }
         SB_ATT();
@@ -222,7 +235,7 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int kt = 0; kt < HK; ++kt)
-                s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
+                s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[SEP ? q : 0][kt])) : (h2 == 0) ? MFMAH(ka[SEP ? q : 0][kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[SEP ? q : 0][kt], qb[q], negm[q]);
         if (TV < 16 * NKT && h2 == NH - 1) {       // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -248,7 +261,7 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
                     // "score - m" comes from the matrix cores again: 8 issue cycles per tile instead of four subtractions (16)
                     if (!SAFE && !(TV < 16 * NKT && NH == 1)) {
 #pragma unroll
-                        for (int kt = 0; kt < HK; ++kt) s[q][kt] = MFMAH(ka[kt], qb[q], negm[q]);
+                        for (int kt = 0; kt < HK; ++kt) s[q][kt] = MFMAH(ka[SEP ? q : 0][kt], qb[q], negm[q]);
                     } else {                                      // (a single-pass block has already masked its phantom keys in s)
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
@@ -279,8 +292,8 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
 #pragma unroll
             for (int kb = 0; kb < HB; ++kb) {
                 if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
-                oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                if (LO) oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                oH[q] = MFMAH(va[SEP ? q : 0][kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                if (LO) oL[q] = MFMAH(va[SEP ? q : 0][kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
                 if (!(S2S_ABL & 64)) {
                 lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
                 if (LO) lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
@@ -304,17 +317,18 @@ __device__ __forceinline__ void load_unit_h(f32x4 (&f)[4], const float* __restri
 }
 
 // One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
-template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
+template <int NQ, int WAVES, int NKT, int TV, bool LO = true, bool SEP = false>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr) {
-    using G = AttnLdsH<NQ, WAVES, NKT>;
+    using G = AttnLdsH<NQ, WAVES, NKT, SEP>;
+    static_assert(!SEP || (WAVES == 1 && NKT == 1), "SEP: every time tile is a one-tile sequence owned by this wave");
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
     _Float16* __restrict__ Vl = reinterpret_cast<_Float16*>(lds + G::K_BYTES);
-    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + wave * G::Q_WAVE_BYTES);
+    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + (SEP ? NQ : 1) * (G::K_BYTES + G::V_BYTES) + wave * G::Q_WAVE_BYTES);
     constexpr int UF = LO ? 1024 : 512;             // floats per weight unit: hi+lo fragments, or the hi-only stream
     const float* ws = W + (LO ? L.stream_h : L.stream_f) + lane * 4;
     f32x4 fa[4], fb[4];
@@ -324,7 +338,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { xb[q][0] = split8<LO>(X[q][0], X[q][1], one); xb[q][1] = split8<LO>(X[q][2], X[q][3], one); }
 
-    if (!(S2S_ABL & 4)) __syncthreads();              // every wave is done reading the previous block's K/V
+    if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // every wave is done reading the previous block's K/V
     DIAG_STAMP(0);
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
 #pragma unroll 1
@@ -349,16 +363,17 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         const int vrow = (2 * p + (c >> 3)) * 16 + (c & 7);    // V^T row of this lane's feature (hi; lo is 8 rows below)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int key = 16 * (qt0 + q) + c;
+            const int T = SEP ? 0 : qt0 + q;                          // the tile's place in its sequence
+            const int sq = SEP ? q * G::SEQ_HALVES : 0;               // ... and the sequence's K/V images
+            const int key = 16 * T + c;
             h4 hi, lo;
             split4<LO>(ak[q] + bk, one, hi, lo);
-            *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
-            *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
+            *reinterpret_cast<h4*>(Kl + sq + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
+            *reinterpret_cast<h4*>(Kl + sq + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
             split4<LO>(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
-            const int T = qt0 + q;                                    // (position inside the row: see AttnLdsH::VS)
-            const int vcol = G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;
-            *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
-            *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
+            const int vcol = G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
+            *reinterpret_cast<h4*>(Vl + sq + vrow * G::VS + vcol) = hi;
+            *reinterpret_cast<h4*>(Vl + sq + (vrow + 8) * G::VS + vcol) = lo;
         }
     }
     // ---- fc accumulator starts as bias + residual (layers.py:85-86)
@@ -370,7 +385,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
     DIAG_STAMP(1);
-    if (!(S2S_ABL & 4)) __syncthreads();              // K/V of every wave visible
+    if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // K/V of every wave visible
     DIAG_STAMP(2);
 
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
@@ -415,7 +430,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + (G::V128 ? 8 : 4) * g;   // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
-                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0, LO, SEP>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
 #if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)   // (NO_FALLBACK: test-only build, proves test_peaked_attention... needs the redo)
                 {
                     bool bad = false;                          // inf or NaN row sum: some P_hi left the f16 range
@@ -425,7 +440,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #ifdef S2S_DIAG
                     if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
 #endif
-                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO, SEP>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
                 }
 #endif
 #pragma unroll

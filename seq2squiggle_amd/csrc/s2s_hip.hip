@@ -13,142 +13,227 @@
 #include "../../include/s2s_hip.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 // ================================================================================ frontend
-template <int MT>
-__device__ __forceinline__ void relu_tiles(f32x4 (&x)[1][MT]) {
+template <int NQ>
+__device__ __forceinline__ void relu_tiles(f32x4 (&x)[NQ][4]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[0][mt][r] = fmaxf(x[0][mt][r], 0.0f);
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[q][mt][r] = fmaxf(x[q][mt][r], 0.0f);
 }
 
-// Linear(64,64)+ReLU+Linear(64,1)+Softplus on emb_out (modules.py:267-278, 182-195).
-template <int MODE>
-__device__ __forceinline__ float mlp_head(const float* __restrict__ W, const MlpOff m, const f32x4 (&s)[1][4],
-                                          const HL (&sb)[1][2], int lane) {
+// Linear(64,64)+ReLU+Linear(64,1)+Softplus on emb_out (modules.py:267-278, 182-195), NQ time tiles.
+template <int MODE, int NQ>
+__device__ __forceinline__ void mlp_head(const float* __restrict__ W, const MlpOff m, const f32x4 (&s)[NQ][4],
+                                         const HL (&sb)[NQ][2], int lane, float (&out)[NQ]) {
     const int g = lane >> 4;
-    f32x4 hid[1][4];
+    f32x4 hid[NQ][4];
     if (MODE == 1) {
-        linear64_h(W + m.w0h, W + m.b0, lane, sb, hid);
+        linear64_h<NQ>(W + m.w0h, W + m.b0, lane, sb, hid);
     } else {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) hid[0][mt] = ldg4(W + m.b0 + 16 * mt + 4 * g);
-        gemm_acc<1, 4, 4>(W + m.w0, lane, hid, s);
-    }
-    relu_tiles<4>(hid);
-    float part = 0.0f;
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = ldg4(W + m.b0 + 16 * mt + 4 * g);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 w = ldg4(W + m.w3 + 16 * mt + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += hid[0][mt][r] * w[r];
+            for (int q = 0; q < NQ; ++q) hid[q][mt] = b;
+        }
+        gemm_acc<NQ, 4, 4>(W + m.w0, lane, hid, s);
     }
-    return softplus_t(sum_g(part) + W[m.b3]);
+    relu_tiles<NQ>(hid);
+    f32x4 w[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) w[mt] = ldg4(W + m.w3 + 16 * mt + 4 * g);
+    const float b3 = W[m.b3];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float part = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += hid[q][mt][r] * w[mt][r];
+        out[q] = softplus_t(sum_g(part) + b3);
+    }
 }
 
 __device__ __forceinline__ int base_code(unsigned char ch) {       // utils.py:74 letter_to_int
     return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'T' ? 4 : ch == '_' ? 0 : -1;
 }
 
-template <int MODE>   // 0: f32-input MFMA, 1: split-f16 (s2s_device_h.h)
-__global__ __launch_bounds__(64) void s2s_frontend_kernel(
-    const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
-    const long long* __restrict__ chunk_start, const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
-    const float* __restrict__ inj_g, const float* __restrict__ inj_zdw, float* __restrict__ ws_enc,
-    float* __restrict__ ws_sigma, int* __restrict__ out_dur, DebugDev dbg, long long dbg_base) {
-    constexpr int LDS_BYTES = (MODE == 1) ? AttnLdsH<1, 1, 1>::BYTES : AttnLds<1>::BYTES;
-    __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+// LDS one wave needs for the encoder blocks of its NQ chunks
+template <int MODE, int NQ> struct FrontLds {
+    static constexpr int BYTES = (MODE == 1) ? AttnLdsH<NQ, 1, 1, (NQ > 1)>::BYTES : AttnLds<1>::BYTES;
+};
+
+// One chunk as the frontend sees it.  bp: its 16+k-1 bases; inj_g / inj_zdw: its 16 injected variates (or null); slot: where
+// the decoder picks it up -- enc_out [16][64], sigma [16] at +1024, dur [16] (int32) at +1040; out_dur: the caller's [16] row;
+// dbg_idx: its row in the debug arrays; live = false: a filler (an odd chunk count), computed and thrown away.
+struct FrontChunk {
+    const uint8_t* bp;
+    int nv;
+    unsigned long long chunk;
+    const float* inj_g;
+    const float* inj_zdw;
+    float* slot;
+    int* out_dur;
+    long long dbg_idx;
+    bool live;
+};
+#define S2S_SLOT_FLOATS (1024 + 16 + 16)
+
+// The frontend of NQ chunks, run by ONE wave (T = 16: every chunk is a single time tile and a sequence of its own): embedding,
+// pre-net, encoder blocks, the three heads and the dwell source.  `lds_raw`: FrontLds<MODE, NQ>::BYTES owned by this wave.
+// Two chunks per wave halve the weight bytes the wave pulls through the vector L1 per chunk and give the in-order wave two
+// independent dependency chains to interleave.
+template <int MODE, int NQ>   // 0: f32-input MFMA (NQ = 1), 1: split-f16 (s2s_device_h.h)
+__device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* __restrict__ W, const FrontChunk (&io)[NQ],
+                                                const ParamsDev& P, char* __restrict__ lds_raw, const DebugDev& dbg,
+                                                const int lane, const float one) {
+    static_assert(MODE == 1 || NQ == 1, "the f32 block has no per-tile sequences");
     float* lds = reinterpret_cast<float*>(lds_raw);
-    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
-    asm volatile("" : "+s"(one));
-    const int b = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const int k = M.k, nb = S2S_T_ENC + k - 1;
-    // chunk b's 16+k-1 bytes: a row of the dense [B][16+k-1] array, or a window of the packed read buffer
-    const uint8_t* bp = chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb;
-    const int nv = n_valid[b];
+    const int g = lane >> 4, c = lane & 15;
+    const int k = M.k;
+#ifdef S2S_DIAG
+    unsigned long long* diag_buf = dbg.diag ? dbg.diag + 32 : nullptr;
+    unsigned long long* diag_blk = dbg.diag ? dbg.diag + 16 : nullptr;
+#else
+    unsigned long long* diag_blk = nullptr;
+#endif
+    DIAG_DECL;
 
     // ---- src_emb on the one-hot k-mer == bias + sum of k gathered columns of W_emb (modules.py:70-73)
-    f32x4 X[1][4];
+    f32x4 X[NQ][4];
+    {
+        f32x4 eb[4];
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) X[0][ft] = ldg4(W + M.emb_b + 16 * ft + 4 * g);
+        for (int ft = 0; ft < 4; ++ft) eb[ft] = ldg4(W + M.emb_b + 16 * ft + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) X[q][ft] = eb[ft];
+    }
     for (int j = 0; j < k; ++j) {
-        const int code = (c < nv) ? base_code(bp[c + j]) : 0;       // pad k-mer = "_" * k (utils.py:342-347)
-        const float* row = W + M.emb_wt + (5 * j + (code < 0 ? 0 : code)) * 64 + 4 * g;
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const f32x4 w = ldg4(row + 16 * ft);
-            if (code >= 0) X[0][ft] += w;                            // unknown letter: all-zero one-hot row (utils.py:86)
+        for (int q = 0; q < NQ; ++q) {
+            const int code = (c < io[q].nv) ? base_code(io[q].bp[c + j]) : 0;   // pad k-mer = "_" * k (utils.py:342-347)
+            const float* row = W + M.emb_wt + (5 * j + (code < 0 ? 0 : code)) * 64 + 4 * g;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const f32x4 w = ldg4(row + 16 * ft);
+                if (code >= 0) X[q][ft] += w;                        // unknown letter: all-zero one-hot row (utils.py:86)
+            }
         }
     }
-    relu_tiles<4>(X);
+    relu_tiles<NQ>(X);
+    DIAG_STAMP(0);
 #pragma unroll 1
     for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
-        f32x4 Y[1][4];
+        f32x4 Y[NQ][4];
         if (MODE == 1) {
-            HL xb[1][2];
-            xb[0][0] = split8(X[0][0], X[0][1], one); xb[0][1] = split8(X[0][2], X[0][3], one);
-            linear64_h(W + M.pre_wh[i], W + M.pre_b[i], lane, xb, Y);
+            HL xb[NQ][2];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
+            linear64_h<NQ>(W + M.pre_wh[i], W + M.pre_b[i], lane, xb, Y);
         } else {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) Y[0][mt] = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
-            gemm_acc<1, 4, 4>(W + M.pre_w[i], lane, Y, X);
-        }
-        relu_tiles<4>(Y);
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 b = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) X[0][mt] = Y[0][mt];
+                for (int q = 0; q < NQ; ++q) Y[q][mt] = b;
+            }
+            gemm_acc<NQ, 4, 4>(W + M.pre_w[i], lane, Y, X);
+        }
+        relu_tiles<NQ>(Y);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) X[q][mt] = Y[q][mt];
     }
-    f32x4 S[1][4];                                                   // emb_out
+    f32x4 S[NQ][4];                                                  // emb_out
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
-        S[0][ft] = X[0][ft];
-        X[0][ft] += ldg4(W + M.pe_enc + c * 64 + 16 * ft + 4 * g);  // modules.py:80
+        const f32x4 pe = ldg4(W + M.pe_enc + c * 64 + 16 * ft + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            S[q][ft] = X[q][ft];
+            X[q][ft] += pe;                                          // modules.py:80
+        }
     }
     if (dbg.emb_out) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-            *reinterpret_cast<f32x4*>(dbg.emb_out + ((dbg_base + b) * 16 + c) * 64 + 16 * ft + 4 * g) = S[0][ft];
+        for (int q = 0; q < NQ; ++q)
+            if (io[q].live)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    *reinterpret_cast<f32x4*>(dbg.emb_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = S[q][ft];
     }
+    DIAG_STAMP(1);
 #pragma unroll 1
     for (int l = 0; l < M.enc_layers; ++l) {
-        if (MODE == 1) fft_block_h<1, 1, 1, 16>(W, M.enc[l], X, lds_raw, 0, 0, lane, one);
-        else           fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane);
+        if constexpr (MODE == 1) fft_block_h<NQ, 1, 1, 16, true, (NQ > 1)>(W, M.enc[l], X, lds_raw, 0, 0, lane, one, diag_blk);
+        else                     fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane, diag_blk);
     }
-    HL Sb[1][2];                                                     // emb_out as a B operand for the three heads
-    if (MODE == 1) { Sb[0][0] = split8(S[0][0], S[0][1], one); Sb[0][1] = split8(S[0][2], S[0][3], one); }
+    DIAG_STAMP(2);
+    HL Sb[NQ][2];                                                    // emb_out as a B operand for the three heads
+    if (MODE == 1) {
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-        *reinterpret_cast<f32x4*>(ws_enc + ((size_t)b * 16 + c) * 64 + 16 * ft + 4 * g) = X[0][ft];
-    if (dbg.enc_out) {
+        for (int q = 0; q < NQ; ++q) { Sb[q][0] = split8(S[q][0], S[q][1], one); Sb[q][1] = split8(S[q][2], S[q][3], one); }
+    }
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-            *reinterpret_cast<f32x4*>(dbg.enc_out + ((dbg_base + b) * 16 + c) * 64 + 16 * ft + 4 * g) = X[0][ft];
+    for (int q = 0; q < NQ; ++q) {
+        if (!io[q].live) continue;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(io[q].slot + c * 64 + 16 * ft + 4 * g) = X[q][ft];
+        if (dbg.enc_out) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                *reinterpret_cast<f32x4*>(dbg.enc_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = X[q][ft];
+        }
     }
 
-    // ---- NoiseSampler (modules.py:275-278)
-    const float sigma = mlp_head<MODE>(W, M.noise, S, Sb, lane);
-    if (g == 0) {
-        ws_sigma[b * 16 + c] = sigma;
-        if (dbg.sigma) dbg.sigma[(dbg_base + b) * 16 + c] = sigma;
+    // ---- NoiseSampler (modules.py:275-278).  Every lane group holds the heads' values of all tiles (sum_g is an all-reduce),
+    //      so from here on lane group q finishes chunk q: ONE pass of the dwell sampler per wave.
+    DIAG_STAMP(3);
+    float sig[NQ];
+    mlp_head<MODE, NQ>(W, M.noise, S, Sb, lane, sig);
+    float sigma = sig[0];
+    FrontChunk me = io[0];
+#pragma unroll
+    for (int q = 1; q < NQ; ++q)
+        if (g == q) { sigma = sig[q]; me = io[q]; }
+    const bool mine = g < NQ && me.live;
+    if (mine) {
+        me.slot[1024 + c] = sigma;
+        if (dbg.sigma) dbg.sigma[me.dbg_idx * 16 + c] = sigma;
     }
     // ---- dwell source (modules.py:396-438)
     float gv;
     if (P.duration_sampling) {
-        const float conc = fmaxf(mlp_head<MODE>(W, M.conc, S, Sb, lane), 1e-8f);      // modules.py:215-216
-        const float rate = fmaxf(mlp_head<MODE>(W, M.rate, S, Sb, lane), 1e-8f);      // modules.py:217-218
-        if (g == 0) {
-            if (dbg.conc) dbg.conc[(dbg_base + b) * 16 + c] = conc;
-            if (dbg.rate) dbg.rate[(dbg_base + b) * 16 + c] = rate;
+        float cq[NQ], rq[NQ];
+        mlp_head<MODE, NQ>(W, M.conc, S, Sb, lane, cq);
+        mlp_head<MODE, NQ>(W, M.rate, S, Sb, lane, rq);
+        float conc = cq[0], rate = rq[0];
+#pragma unroll
+        for (int q = 1; q < NQ; ++q)
+            if (g == q) { conc = cq[q]; rate = rq[q]; }
+        conc = fmaxf(conc, 1e-8f);                                   // modules.py:215-216
+        rate = fmaxf(rate, 1e-8f);                                   // modules.py:217-218
+        DIAG_STAMP(4);
+        if (mine) {
+            if (dbg.conc) dbg.conc[me.dbg_idx * 16 + c] = conc;
+            if (dbg.rate) dbg.rate[me.dbg_idx * 16 + c] = rate;
         }
-        if (inj_g) {
-            gv = inj_g[b * 16 + c];
+        if (me.inj_g) {
+            gv = mine ? me.inj_g[c] : 1.0f;
         } else {
-            const unsigned long long chunk = (unsigned long long)(first_chunk + b);
             float sg = 0.0f;
-            if (g == 0) sg = standard_gamma(conc, (unsigned)chunk, (unsigned)(chunk >> 32), c, P.seed_lo, P.seed_hi);
+            if (mine) sg = standard_gamma(conc, (unsigned)me.chunk, (unsigned)(me.chunk >> 32), c, P.seed_lo, P.seed_hi);
             gv = fmaxf(sg / rate, 1.17549435e-38f);                 // Gamma.sample: /rate, clamp_(tiny)
         }
         gv = fmaxf(gv, 1.0f);                                       // modules.py:223
@@ -157,21 +242,41 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
         gv = P.dwell_mean;                                          // modules.py:420-423
     } else {
         float z;
-        if (inj_zdw) {
-            z = inj_zdw[b * 16 + c];
+        if (me.inj_zdw) {
+            z = mine ? me.inj_zdw[c] : 0.0f;
         } else {
-            const unsigned long long chunk = (unsigned long long)(first_chunk + b);
-            const u32x4 r = philox4x32_10((unsigned)chunk, (unsigned)(chunk >> 32), c | (S2S_KIND_DWELL << 16), 0,
+            const u32x4 r = philox4x32_10((unsigned)me.chunk, (unsigned)(me.chunk >> 32), c | (S2S_KIND_DWELL << 16), 0,
                                           P.seed_lo, P.seed_hi);
             z = box_muller(r.x, r.y);
         }
-        gv = fmaxf(__fadd_rn(P.dwell_mean, __fmul_rn(z, P.dwell_std)), P.min_duration);   // modules.py:425-432
+        gv = fmaxf(mul_then_add(z, P.dwell_std, P.dwell_mean), P.min_duration);   // modules.py:425-432
     }
-    if (g == 0) {
+    if (mine) {
         const float rd = fminf(fmaxf(rintf(gv), -1.0e9f), 1.0e9f);  // torch.round: half-to-even (modules.py:437)
-        out_dur[b * 16 + c] = (int)rd;
-        if (dbg.g) dbg.g[(dbg_base + b) * 16 + c] = gv;
+        reinterpret_cast<int*>(me.slot + 1040)[c] = (int)rd;
+        me.out_dur[c] = (int)rd;
+        if (dbg.g) dbg.g[me.dbg_idx * 16 + c] = gv;
     }
+    DIAG_STAMP(5);
+}
+
+// two-launch path: one wave per chunk, enc_out / sigma / dur handed to the decoder kernel through the handle's workspace
+template <int MODE>
+__global__ __launch_bounds__(64) void s2s_frontend_kernel(
+    const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
+    const long long* __restrict__ chunk_start, const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
+    const float* __restrict__ inj_g, const float* __restrict__ inj_zdw, float* __restrict__ ws_slots,
+    int* __restrict__ out_dur, DebugDev dbg, long long dbg_base) {
+    __shared__ __attribute__((aligned(16))) char lds_raw[FrontLds<MODE, 1>::BYTES];
+    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
+    asm volatile("" : "+s"(one));
+    const int b = blockIdx.x, nb = S2S_T_ENC + M.k - 1;
+    // chunk b's 16+k-1 bytes: a row of the dense [B][16+k-1] array, or a window of the packed read buffer
+    const FrontChunk io[1] = {{chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb, n_valid[b],
+                               (unsigned long long)(first_chunk + b), inj_g ? inj_g + b * 16 : nullptr,
+                               inj_zdw ? inj_zdw + b * 16 : nullptr, ws_slots + (size_t)b * S2S_SLOT_FLOATS, out_dur + b * 16,
+                               dbg_base + b, true}};
+    frontend_chunks<MODE, 1>(M, W, io, P, lds_raw, dbg, threadIdx.x, one);
 }
 
 // ================================================================================ decoder
@@ -184,76 +289,87 @@ __global__ __launch_bounds__(64) void s2s_frontend_kernel(
 static constexpr int DEC_LDS_F32 = AttnLds<DEC_NKT>::BYTES;
 static constexpr int DEC_LDS_H = AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>::BYTES;
 
-template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h), 3: the same block with single f16 products
-__global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
-    const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_enc,
-    const float* __restrict__ ws_sigma, const int* __restrict__ dur, int n_chunks, long long first_chunk, ParamsDev P,
-    const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    float* lds = reinterpret_cast<float*>(lds_raw);
-    // persistent workgroups (LDS allows one per CU): each walks the chunk list with stride gridDim.x, so a CU
-    // never waits for a workgroup to drain, be re-dispatched and re-allocate 148 KB of LDS between chunks
-#pragma unroll 1
-    for (int b = blockIdx.x; b < n_chunks; b += gridDim.x) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const int qt0 = DEC_NQ * wave;
-    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
-    asm volatile("" : "+s"(one));
+// The decoder of ONE chunk, run by the 8 waves of a workgroup, in three pieces so that the fused kernel can request the next
+// chunk's rows before it finishes the current one: dec_gather (length regulator), dec_blocks, dec_emit (projection, noise).
+// slot: the chunk's frontend outputs -- enc_out [16][64], sigma [16] at +1024, dur [16] (int32) at +1040.
 
-    // ---- length regulator (modules.py:344-392) as a gather: row t copies encoder row
-    //      i(t) = #{j : cum[j] <= t}; rows past cum[15] are zero; crop at 250; then + position_enc
-    //      (modules.py:136, also on the zero rows)
-#ifdef S2S_DIAG
-    unsigned long long* diag_buf = dbg.diag;
-#endif
-    DIAG_DECL;
+// ---- length regulator (modules.py:344-392) as a gather: row t copies encoder row i(t) = #{j : cum[j] <= t}; rows past
+//      cum[15] are zero; crop at 250; then + position_enc (modules.py:136, also on the zero rows).  Two halves: dec_gather_issue
+//      requests the rows, dec_gather_finish combines them -- whatever the caller puts in between runs under the loads.
+struct GatherRaw {
+    f32x4 e[DEC_NQ][4], pe[DEC_NQ][4];
+    float sg[DEC_NQ];
+    int idx[DEC_NQ];
+};
+__device__ __forceinline__ void dec_gather_issue(const ModelDev& M, const float* __restrict__ W, const float* __restrict__ slot,
+                                                 const int wave, const int lane, GatherRaw& R) {
+    const int g = lane >> 4, c = lane & 15;
+    const int qt0 = DEC_NQ * wave;
     int cum[16];
     {
+        // a lane-indexed (vector) load, then broadcasts: in the fused kernel the dwell counts were stored by another wave of
+        // this launch, and a uniform-address load could be served from the scalar cache, which vector stores do not update
+        const int dv = reinterpret_cast<const int*>(slot + 1040)[c];
         int run = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {          // a dwell past the crop at 250 (modules.py:386) acts like 251: no int32 overflow
-            const int dj = dur[b * 16 + j];
+            const int dj = __builtin_amdgcn_readlane(dv, j);
             run += dj < S2S_T_DEC + 1 ? dj : S2S_T_DEC + 1;
             cum[j] = run;
         }
     }
-    f32x4 X[DEC_NQ][4];
-    float sig_ext[DEC_NQ];
 #pragma unroll
     for (int q = 0; q < DEC_NQ; ++q) {
         const int t = 16 * (qt0 + q) + c;
         int idx = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) idx += (cum[j] <= t) ? 1 : 0;
-        const bool live = idx < 16, real = t < S2S_T_DEC;
-        const float* er = ws_enc + ((size_t)b * 16 + (live ? idx : 0)) * 64 + 4 * g;
-        const float* pr = W + M.pe_dec + (real ? t : 0) * 64 + 4 * g;
+        R.idx[q] = idx;
+        const int row = idx < 16 ? idx : 0;
+        const float* er = slot + row * 64 + 4 * g;
+        const float* pr = W + M.pe_dec + (t < S2S_T_DEC ? t : 0) * 64 + 4 * g;
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const f32x4 e = ldg4(er + 16 * ft), pe = ldg4(pr + 16 * ft);
-            X[q][ft] = real ? ((live ? e : f32x4{0, 0, 0, 0}) + pe) : f32x4{0, 0, 0, 0};
-        }
-        sig_ext[q] = live ? ws_sigma[b * 16 + (live ? idx : 0)] : 0.0f;
+        for (int ft = 0; ft < 4; ++ft) { R.e[q][ft] = ldg4(er + 16 * ft); R.pe[q][ft] = ldg4(pr + 16 * ft); }
+        R.sg[q] = slot[1024 + row];
     }
-    DIAG_STAMP(8);
+}
+__device__ __forceinline__ void dec_gather_finish(const GatherRaw& R, const int wave, const int lane, f32x4 (&X)[DEC_NQ][4],
+                                                  float (&sig_ext)[DEC_NQ]) {
+    const int c = lane & 15;
+#pragma unroll
+    for (int q = 0; q < DEC_NQ; ++q) {
+        const int t = 16 * (DEC_NQ * wave + q) + c;
+        const bool live = R.idx[q] < 16, real = t < S2S_T_DEC;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+            X[q][ft] = real ? ((live ? R.e[q][ft] : f32x4{0, 0, 0, 0}) + R.pe[q][ft]) : f32x4{0, 0, 0, 0};
+        sig_ext[q] = live ? R.sg[q] : 0.0f;
+    }
+}
+
+template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h), 3: the same block with single f16 products
+__device__ __forceinline__ void dec_blocks(const ModelDev& M, const float* __restrict__ W, f32x4 (&X)[DEC_NQ][4],
+                                           char* __restrict__ lds_raw, const int wave, const int lane, const float one,
+                                           unsigned long long* diag) {
+    const int qt0 = DEC_NQ * wave;
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
-        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
-        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, dbg.diag);
-        else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds, qt0, lane, dbg.diag);
+        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag);
+        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag);
+        else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, reinterpret_cast<float*>(lds_raw), qt0, lane, diag);
     }
+}
 
-    // ---- out_linear + ReLU (modules.py:140-141), x165 (model.py:221), noise where != 0
-    //      (model.py:224-238), clamp (model.py:240)
-    DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
+// ---- out_linear + ReLU (modules.py:140-141).  Every lane group ends up with the row sums of all tiles (sum_g is an
+//      all-reduce), so lane group q keeps tile q: ys = its sample (scaled units), se = its expanded sigma.
+__device__ __forceinline__ void dec_project(const ModelDev& M, const float* __restrict__ W, const f32x4 (&X)[DEC_NQ][4],
+                                            const float (&sig_ext)[DEC_NQ], const int lane, float& ys, float& se) {
+    const int g = lane >> 4;
     f32x4 wo[4];
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) wo[ft] = ldg4(W + M.out_w + 16 * ft + 4 * g);
     const float bo = W[M.out_b];
-    // every lane group ends up with the row sums of all tiles (sum_g is an all-reduce), so lane group q finishes tile q:
-    // ONE pass of Philox + Box-Muller per wave for its DEC_NQ <= 4 tiles
-    float ys = 0.0f, se = 0.0f;
+    ys = 0.0f; se = 0.0f;
 #pragma unroll
     for (int q = 0; q < DEC_NQ; ++q) {
         float part = 0.0f;
@@ -264,32 +380,163 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
         const float v = fmaxf(sum_g(part) + bo, 0.0f);
         if (g == q) { ys = v; se = sig_ext[q]; }
     }
-    {
-        const int t = 16 * (qt0 + g) + c;
-        float y = __fmul_rn(ys, M.scale);
-        if (g < DEC_NQ && t < S2S_T_DEC) {
-            if (dbg.y_scaled) dbg.y_scaled[(dbg_base + b) * S2S_T_DEC + t] = ys;
-            if (P.noise_std > 0.0f) {
-                float z;
-                if (inj_z01) {
-                    z = inj_z01[(size_t)b * S2S_T_DEC + t];
-                } else {
-                    const unsigned long long chunk = (unsigned long long)(first_chunk + b);
-                    const u32x4 r = philox4x32_10((unsigned)chunk, (unsigned)(chunk >> 32),
-                                                  (unsigned)t | (S2S_KIND_NOISE << 16), 0, P.seed_lo, P.seed_hi);
-                    z = box_muller(r.x, r.y);
-                }
-                if (dbg.z01) dbg.z01[(dbg_base + b) * S2S_T_DEC + t] = z;
-                const float sd = P.noise_sampling
-                                     ? __fmul_rn(__fmul_rn(fmaxf(se, P.min_noise), P.noise_std), M.scale)
-                                     : P.noise_std;
-                if (y != 0.0f) y = __fadd_rn(y, __fmul_rn(z, sd));
+}
+
+// ---- x165 (model.py:221), noise where != 0 (model.py:224-238), clamp (model.py:240): ONE pass of Philox + Box-Muller per
+//      wave for its DEC_NQ <= 4 tiles.  inj_z01 / out_signal: the chunk's [250] rows.
+__device__ __forceinline__ void dec_emit(const ModelDev& M, const float ys, const float se, const unsigned long long chunk,
+                                         const ParamsDev& P, const float* __restrict__ inj_z01, float* __restrict__ out_signal,
+                                         const DebugDev& dbg, const long long dbg_idx, const int wave, const int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int t = 16 * (DEC_NQ * wave + g) + c;
+    float y = __fmul_rn(ys, M.scale);
+    if (g < DEC_NQ && t < S2S_T_DEC) {
+        if (dbg.y_scaled) dbg.y_scaled[dbg_idx * S2S_T_DEC + t] = ys;
+        if (P.noise_std > 0.0f) {
+            float z;
+            if (inj_z01) {
+                z = inj_z01[t];
+            } else {
+                const u32x4 r = philox4x32_10((unsigned)chunk, (unsigned)(chunk >> 32),
+                                              (unsigned)t | (S2S_KIND_NOISE << 16), 0, P.seed_lo, P.seed_hi);
+                z = box_muller(r.x, r.y);
             }
-            out_signal[(size_t)b * S2S_T_DEC + t] = fmaxf(y, 0.0f);
+            if (dbg.z01) dbg.z01[dbg_idx * S2S_T_DEC + t] = z;
+            const float sd = P.noise_sampling
+                                 ? __fmul_rn(__fmul_rn(fmaxf(se, P.min_noise), P.noise_std), M.scale)
+                                 : P.noise_std;
+            if (y != 0.0f) y = mul_then_add(z, sd, y);
+        }
+        out_signal[t] = fmaxf(y, 0.0f);
+    }
+}
+
+// two-launch path: persistent workgroups (LDS allows one per CU), each walks the chunk list with stride gridDim.x, so a CU
+// never waits for a workgroup to drain, be re-dispatched and re-allocate 148 KB of LDS between chunks
+template <int MODE>
+__global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
+    const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_slots, int n_chunks, long long first_chunk,
+    ParamsDev P, const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#pragma unroll 1
+    for (int b = blockIdx.x; b < n_chunks; b += gridDim.x) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
+        asm volatile("" : "+s"(one));
+        const float* slot = ws_slots + (size_t)b * S2S_SLOT_FLOATS;
+#ifdef S2S_DIAG
+        unsigned long long* diag_buf = dbg.diag;
+#endif
+        DIAG_DECL;
+        f32x4 X[DEC_NQ][4];
+        float sig_ext[DEC_NQ], ys, se;
+        {
+            GatherRaw R;
+            dec_gather_issue(M, W, slot, wave, lane, R);
+            dec_gather_finish(R, wave, lane, X, sig_ext);
+        }
+        DIAG_STAMP(8);
+        dec_blocks<MODE>(M, W, X, lds_raw, wave, lane, one, dbg.diag);
+        DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
+        dec_project(M, W, X, sig_ext, lane, ys, se);
+        dec_emit(M, ys, se, (unsigned long long)(first_chunk + b), P, inj_z01 ? inj_z01 + (size_t)b * S2S_T_DEC : nullptr,
+                 out_signal + (size_t)b * S2S_T_DEC, dbg, dbg_base + b, wave, lane);
+        DIAG_STAMP(9);
+    }
+}
+
+// Fused path (default): ONE launch per tile of chunks, nothing but the bases comes in and nothing but dwell counts and
+// signal goes out.  A persistent 8-wave workgroup owns a contiguous range of the tile's chunks and walks it in groups of up
+// to 8 * FNQ: wave w runs the one-wave frontend of chunks FNQ*w .. FNQ*w+FNQ-1 of the group (their encoder K/V in a slice of
+// the decoder's K/V region, dead between chunks), then all 8 waves decode the group's chunks one after the other.  The
+// frontend outputs of a group (4.2 KB per chunk) wait in the workgroup's own slots of `handoff` -- rewritten every group by the
+// CU that reads them back, so they live in that XCD's L2 and HBM sees them only as an occasional write-back.
+template <int MODE> struct Fused {
+    static constexpr int FMODE = (MODE == 3) ? 1 : MODE;          // the reduced-precision decoder keeps the f16x3 frontend
+    static constexpr int FNQ = (FMODE == 1) ? 2 : 1;              // chunks per frontend wave
+    static constexpr int GROUP = DEC_WAVES * FNQ;
+    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H;
+    static_assert(DEC_WAVES * FrontLds<FMODE, FNQ>::BYTES <= LDS, "the frontend waves' K/V images share the decoder's LDS");
+};
+#define S2S_MAX_GROUP (2 * DEC_WAVES)
+// TEST = false is the production instance: no injected variates and no stage outputs, whose address arithmetic would otherwise
+// sit (and spill) in the hot loop; the parity tests that inject or ask for stage outputs run the TEST = true instance of the
+// same code.
+template <int MODE, bool TEST>
+__global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
+    const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
+    const long long* __restrict__ chunk_start, const uint8_t* __restrict__ n_valid, int n_chunks, long long first_chunk,
+    ParamsDev P, const float* __restrict__ inj_g_, const float* __restrict__ inj_zdw_, const float* __restrict__ inj_z01_,
+    float* __restrict__ handoff, int* __restrict__ out_dur, float* __restrict__ out_signal, DebugDev dbg_, long long dbg_base) {
+    using F = Fused<MODE>;
+    const float* const inj_g = TEST ? inj_g_ : nullptr;
+    const float* const inj_zdw = TEST ? inj_zdw_ : nullptr;
+    const float* const inj_z01 = TEST ? inj_z01_ : nullptr;
+    DebugDev dbg = dbg_;
+    if (!TEST) { dbg = DebugDev{}; dbg.diag = dbg_.diag; }
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nb = S2S_T_ENC + M.k - 1;
+    float* const slot0 = handoff + (size_t)blockIdx.x * S2S_MAX_GROUP * S2S_SLOT_FLOATS;
+    const int lo = (int)((long long)blockIdx.x * n_chunks / gridDim.x), hi = (int)((long long)(blockIdx.x + 1) * n_chunks / gridDim.x);
+#pragma unroll 1
+    for (int g0 = lo; g0 < hi; g0 += F::GROUP) {
+        const int n_here = hi - g0 < F::GROUP ? hi - g0 : F::GROUP;
+        float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
+        asm volatile("" : "+s"(one));
+#ifdef S2S_DIAG
+        unsigned long long* diag_buf = dbg.diag;
+#endif
+        DIAG_DECL;
+        __syncthreads();                   // the previous group's last block is done with the K/V region and with the slots
+        if (F::FNQ * wave < n_here) {
+            FrontChunk io[F::FNQ];
+#pragma unroll
+            for (int q = 0; q < F::FNQ; ++q) {
+                const int j = F::FNQ * wave + q;
+                const bool live = j < n_here;
+                const int b = g0 + (live ? j : F::FNQ * wave);       // a filler repeats the wave's first chunk
+                io[q] = FrontChunk{chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb, n_valid[b],
+                                   (unsigned long long)(first_chunk + b), inj_g ? inj_g + (size_t)b * 16 : nullptr,
+                                   inj_zdw ? inj_zdw + (size_t)b * 16 : nullptr, slot0 + j * S2S_SLOT_FLOATS,
+                                   out_dur + (size_t)b * 16, dbg_base + b, live};
+            }
+            frontend_chunks<F::FMODE, F::FNQ>(M, W, io, P, lds_raw + wave * FrontLds<F::FMODE, F::FNQ>::BYTES, dbg, lane, one);
+        }
+        __syncthreads();                   // the group's slots are written (global stores: workgroup-scope release/acquire)
+        DIAG_STAMP(7);                     // frontend phase and its two barriers
+        f32x4 X[DEC_NQ][4];
+        float sig_ext[DEC_NQ];
+        {
+            GatherRaw R;
+            dec_gather_issue(M, W, slot0, wave, lane, R);
+            dec_gather_finish(R, wave, lane, X, sig_ext);
+        }
+        DIAG_STAMP(8);
+#pragma unroll 1
+        for (int j = 0; j < n_here; ++j) {
+            const int b = g0 + j;
+            dec_blocks<MODE>(M, W, X, lds_raw, wave, lane, one, dbg.diag);
+            DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
+            // (an opaque copy of the lane id: the per-lane addresses below are recomputed per chunk, a handful of VALU
+            // instructions, instead of being hoisted out of the loop and spilled across the blocks -- a scratch reload here
+            // would also wait for every load issued before it)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            float ys, se;
+            dec_project(M, W, X, sig_ext, ln, ys, se);
+            // the next chunk's rows are requested before this one's noise is drawn: two dependent L2 round trips hide behind
+            // Philox + Box-Muller (after the group's last chunk: the same chunk again, thrown away)
+            GatherRaw R;
+            dec_gather_issue(M, W, slot0 + (j + 1 < n_here ? j + 1 : j) * S2S_SLOT_FLOATS, wave, ln, R);
+            dec_emit(M, ys, se, (unsigned long long)(first_chunk + b), P, inj_z01 ? inj_z01 + (size_t)b * S2S_T_DEC : nullptr,
+                     out_signal + (size_t)b * S2S_T_DEC, dbg, dbg_base + b, wave, ln);
+            dec_gather_finish(R, wave, ln, X, sig_ext);
+            DIAG_STAMP(9);
         }
     }
-    DIAG_STAMP(9);
-    }   // chunk loop
 }
 
 // ================================================================================ export
@@ -479,8 +726,8 @@ struct s2s_handle {
     size_t arena_floats = 0;
     int tile = 0;                     // chunks per launch pair
     int n_wg = 256;                   // decoder grid: persistent workgroups, one per CU
-    float* ws_enc = nullptr;          // [tile][16][64]
-    float* ws_sigma = nullptr;        // [tile][16]
+    float* handoff = nullptr;         // frontend -> decoder slots: [n_wg][S2S_MAX_GROUP][S2S_SLOT_FLOATS] (L2-resident), or, with
+    bool two_launch = false;          // S2S_TWO_LAUNCH=1 at creation (the unfused two launches, for A/B measurements): [tile] slots
     int* ws_counts = nullptr;         // export scratch, grown on demand outside of launches
     long long* ws_offs = nullptr;
     int ws_export_cap = 0;
@@ -775,20 +1022,23 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(arena)");
     h->tile = 32768;
-    if ((e = hipMalloc(&h->ws_enc, (size_t)h->tile * 16 * 64 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(ws_enc)");
-    if ((e = hipMalloc(&h->ws_sigma, (size_t)h->tile * 16 * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(ws_sigma)");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 AttnLds<DEC_NKT>::BYTES)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute(decoder LDS)");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 DEC_LDS_H)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute(decoder LDS, f16 block)");
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(s2s_decoder_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 DEC_LDS_H)) != hipSuccess)
-        return bail(e, "hipFuncSetAttribute(decoder LDS, f16 single-product block)");
+    if (const char* tl = getenv("S2S_TWO_LAUNCH")) h->two_launch = tl[0] == '1';
+    {
+        const size_t slots = h->two_launch ? (size_t)h->tile : (size_t)h->n_wg * S2S_MAX_GROUP;
+        if ((e = hipMalloc(&h->handoff, slots * S2S_SLOT_FLOATS * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(handoff)");
+    }
+    const struct { const void* fn; int bytes; } dyn_lds[] = {
+        {reinterpret_cast<const void*>(s2s_decoder_kernel<0>), DEC_LDS_F32}, {reinterpret_cast<const void*>(s2s_decoder_kernel<1>), DEC_LDS_H},
+        {reinterpret_cast<const void*>(s2s_decoder_kernel<3>), DEC_LDS_H},   {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), DEC_LDS_F32},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), DEC_LDS_H}, {reinterpret_cast<const void*>(s2s_fused_kernel<3, false>), DEC_LDS_H},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<0, true>), DEC_LDS_F32}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, true>), DEC_LDS_H},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<3, true>), DEC_LDS_H}};
+    for (const auto& k : dyn_lds)
+        if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess)
+            return bail(e, "hipFuncSetAttribute(dynamic LDS)");
 #ifdef S2S_DIAG
-    if ((e = hipMalloc(&h->d_diag, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
-    if ((e = hipMemset(h->d_diag, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
+    if ((e = hipMalloc(&h->d_diag, 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
+    if ((e = hipMemset(h->d_diag, 0, 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
 #endif
     *out = h;
     return S2S_OK;
@@ -799,8 +1049,7 @@ void s2s_destroy(s2s_handle* h) {
     DeviceGuard guard(h->device);
     for (auto& ev : h->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->d_arena) (void)hipFree(h->d_arena);
-    if (h->ws_enc) (void)hipFree(h->ws_enc);
-    if (h->ws_sigma) (void)hipFree(h->ws_sigma);
+    if (h->handoff) (void)hipFree(h->handoff);
     if (h->ws_counts) (void)hipFree(h->ws_counts);
     if (h->ws_offs) (void)hipFree(h->ws_offs);
     if (h->ws_svb) (void)hipFree(h->ws_svb);
@@ -834,35 +1083,46 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
     const int nb = S2S_T_ENC + h->cfg.seq_kmer - 1;
     for (int64_t s = 0; s < B; s += h->tile) {
         const int n = (int)((B - s < h->tile) ? (B - s) : h->tile);
-        if (h->cfg.compute_mode != S2S_MODE_F32)
-            hipLaunchKernelGGL(s2s_frontend_kernel<1>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, chunk_start ? bases : bases + (size_t)s * nb,
-                               reinterpret_cast<const long long*>(chunk_start ? chunk_start + s : nullptr), n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
-                               inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
-        else
-            hipLaunchKernelGGL(s2s_frontend_kernel<0>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, chunk_start ? bases : bases + (size_t)s * nb,
-                               reinterpret_cast<const long long*>(chunk_start ? chunk_start + s : nullptr), n_valid + s, (long long)(first_global_chunk + s), P, inject_g ? inject_g + s * 16 : nullptr,
-                               inject_zdw ? inject_zdw + s * 16 : nullptr, h->ws_enc, h->ws_sigma, out_dur + s * 16, D, (long long)s);
+        const uint8_t* tb = chunk_start ? bases : bases + (size_t)s * nb;
+        const long long* tcs = reinterpret_cast<const long long*>(chunk_start ? chunk_start + s : nullptr);
+        const float* tg = inject_g ? inject_g + s * 16 : nullptr;
+        const float* tzdw = inject_zdw ? inject_zdw + s * 16 : nullptr;
+        const float* tz01 = inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr;
+        float* tsig = out_signal + (size_t)s * S2S_T_DEC;
+        const long long fc = (long long)(first_global_chunk + s);
+        const dim3 grid(n < h->n_wg ? n : h->n_wg), block(DEC_WAVES * 64);
+        const int mode = h->cfg.compute_mode;
         EventPair ev{};
+        if (h->two_launch) {
+            if (mode != S2S_MODE_F32)
+                hipLaunchKernelGGL(s2s_frontend_kernel<1>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, tb, tcs, n_valid + s, fc, P,
+                                   tg, tzdw, h->handoff, out_dur + s * 16, D, (long long)s);
+            else
+                hipLaunchKernelGGL(s2s_frontend_kernel<0>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, tb, tcs, n_valid + s, fc, P,
+                                   tg, tzdw, h->handoff, out_dur + s * 16, D, (long long)s);
+        }
         if (h->profiling) {
             HIP_TRY(h, hipEventCreate(&ev.a));
             HIP_TRY(h, hipEventCreate(&ev.b));
             HIP_TRY(h, hipEventRecord(ev.a, stream));
         }
-        if (h->cfg.compute_mode == S2S_MODE_F16)
-            hipLaunchKernelGGL(s2s_decoder_kernel<3>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
-                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
-                               P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
-                               (long long)s);
-        else if (h->cfg.compute_mode == S2S_MODE_F16X3)
-            hipLaunchKernelGGL(s2s_decoder_kernel<1>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), DEC_LDS_H, stream,
-                               h->model, h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s),
-                               P, inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
-                               (long long)s);
-        else
-            hipLaunchKernelGGL(s2s_decoder_kernel<0>, dim3(n < h->n_wg ? n : h->n_wg), dim3(DEC_WAVES * 64), AttnLds<DEC_NKT>::BYTES, stream, h->model,
-                               h->d_arena, h->ws_enc, h->ws_sigma, out_dur + s * 16, n, (long long)(first_global_chunk + s), P,
-                               inject_z01 ? inject_z01 + (size_t)s * S2S_T_DEC : nullptr, out_signal + (size_t)s * S2S_T_DEC, D,
-                               (long long)s);
+        if (h->two_launch) {
+            if (mode == S2S_MODE_F16)
+                hipLaunchKernelGGL(s2s_decoder_kernel<3>, grid, block, DEC_LDS_H, stream, h->model, h->d_arena, h->handoff, n, fc, P,
+                                   tz01, tsig, D, (long long)s);
+            else if (mode == S2S_MODE_F16X3)
+                hipLaunchKernelGGL(s2s_decoder_kernel<1>, grid, block, DEC_LDS_H, stream, h->model, h->d_arena, h->handoff, n, fc, P,
+                                   tz01, tsig, D, (long long)s);
+            else
+                hipLaunchKernelGGL(s2s_decoder_kernel<0>, grid, block, DEC_LDS_F32, stream, h->model, h->d_arena, h->handoff, n, fc, P,
+                                   tz01, tsig, D, (long long)s);
+        } else {
+            const bool test = dbg || inject_g || inject_zdw || inject_z01;
+            auto fused = test ? (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, true> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, true> : s2s_fused_kernel<0, true>)
+                              : (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, false> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, false> : s2s_fused_kernel<0, false>);
+            hipLaunchKernelGGL(fused, grid, block, mode == S2S_MODE_F32 ? DEC_LDS_F32 : DEC_LDS_H, stream, h->model, h->d_arena, tb, tcs,
+                               n_valid + s, n, fc, P, tg, tzdw, tz01, h->handoff, out_dur + s * 16, tsig, D, (long long)s);
+        }
         if (h->profiling) {
             HIP_TRY(h, hipEventRecord(ev.b, stream));
             ev.chunks = n;
@@ -998,12 +1258,12 @@ int s2s_get_kernel_ms(s2s_handle* h, double* ms_total, int64_t* launches, int64_
     return S2S_OK;
 }
 
-int s2s_diag_read(s2s_handle* h, uint64_t* out16) {
-    if (!h || !out16) return S2S_ERR_ARG;
+int s2s_diag_read(s2s_handle* h, uint64_t* out48) {
+    if (!h || !out48) return S2S_ERR_ARG;
     if (!h->d_diag) return fail(h, S2S_ERR_ARG, "not a diagnostic (-DS2S_DIAG) build");
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out16, h->d_diag, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemset(h->d_diag, 0, 16 * sizeof(uint64_t)));
+    HIP_TRY(h, hipMemcpy(out48, h->d_diag, 48 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemset(h->d_diag, 0, 48 * sizeof(uint64_t)));
     return S2S_OK;
 }
 

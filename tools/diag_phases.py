@@ -16,18 +16,25 @@ rng = np.random.default_rng(0)
 reads = ["".join(rng.choice(list("ACGT"), 5000)) for _ in range(105)]
 bases, nv, _ = S.encode_reads(reads, 9)
 b, n = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda()
-out = (C.c_uint64 * 16)()
+out = (C.c_uint64 * 48)()
 for it in range(2):
     eng.predict_chunks(b, n, S.PredictParams(seed=1))
     _lib.lib().s2s_diag_read(eng._h, out)
 v = list(out)
-names = {0: "entry barrier wait", 1: "K/V GEMM + LDS store", 2: "barrier 2 wait", 3: "attention (Q, S, softmax, PV, fc)",
+front = {32: "frontend: embedding gather", 33: "frontend: pre-net, + PE", 34: "frontend: encoder blocks", 35: "frontend: enc_out stores",
+         36: "frontend: three heads", 37: "frontend: dwell sampler, stores",
+         16: "  enc block: entry", 17: "  enc block: K/V GEMM + LDS store", 18: "  enc block: sync", 19: "  enc block: attention (Q, S, softmax, PV, fc)",
+         20: "  enc block: LN1", 21: "  enc block: FFN", 22: "  enc block: LN2"}
+names = {7: "frontend phase + its two barriers (fused kernel)", 0: "entry barrier wait", 1: "K/V GEMM + LDS store", 2: "barrier 2 wait", 3: "attention (Q, S, softmax, PV, fc)",
          4: "LN1 (+ FFN fill issue, operand split)", 5: "FFN", 6: "LN2", 8: "prologue (LR gather)", 9: "epilogue",
          12: "barrier: attention done (FFN_LDS)", 13: "wait: FFN weights landed", 14: "barrier: weights visible", 15: "blocks total"}
-tot = sum(v[i] for i in (0, 1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 14))
+tot = sum(v[i] for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14))
 nw = bases.shape[0] * 8
 for i in sorted(names):
     print(f"{names[i]:40s} {v[i] / nw:12.0f} cycles/wave  {100 * v[i] / tot:5.1f} %")
 print(f"total {tot / nw:.0f} cycles per wave per chunk")
+print("frontend waves (cycles per frontend wave and chunk; the waves run one frontend per group of chunks):")
+for i in sorted(front):
+    print(f"{front[i]:50s} {v[i] / bases.shape[0]:12.0f}")
 if v[11]:
     print(f"safe-path redos: {v[10]} of {v[11]} (wave, head) softmax runs = {100 * v[10] / v[11]:.2f} %")
