@@ -11,7 +11,7 @@
  *   - all launches are stream-ordered on `stream` (a hipStream_t passed as void*, NULL = default
  *     stream) and asynchronous w.r.t. the host;
  *   - return value 0 = success, negative = error; s2s_last_error() gives the message;
- *   - a handle may be used from one host thread and on one stream at a time (it owns a one-tile workspace that
+ *   - a handle may be used from one host thread and on one stream at a time (it owns the per-workgroup hand-off slots that
  *     consecutive launches reuse in stream order); every call makes the handle's device current for its duration
  *     and restores the caller's; there is no global state.
  */
@@ -193,6 +193,18 @@ int s2s_philox_u32(s2s_handle* h, void* stream, uint64_t seed, uint32_t c0, uint
 int s2s_set_profiling(s2s_handle* h, int32_t enabled);
 int s2s_get_kernel_ms(s2s_handle* h, double* decoder_ms_total, int64_t* decoder_launches,
                       int64_t* decoder_chunks);
+
+/* ---- host-side helper (no GPU work, no handle): frames and compresses one batch of BLOW5 records on `threads` worker
+ * threads -- what pyslow5's write_record_batch(threads = cpu_count) does for the reference (signal_io.py:167-171).
+ * Record i's body is prefix[prefix_offs[i] : prefix_offs[i+1]] + signal[signal_offs[i] : signal_offs[i+1]] +
+ * suffix[suffix_offs[i] : suffix_offs[i+1]] (the fields before and after raw_signal, built by the caller; the signal bytes
+ * are little-endian int16 samples or an svb-zd blob); `out` receives, in record order, [u64 compressed size][body compressed
+ * with `method`: 0 none, 1 zlib container (RFC 1950; written by libdeflate when that library loads, else zlib), 2 zstd] at
+ * `level`.  `capacity` must be at least s2s_blow5_pack_bound(total body bytes, n).  Returns the bytes written, or < 0. */
+int64_t s2s_blow5_pack_bound(int64_t body_bytes_total, int32_t n_records);
+int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const uint8_t* suffix, const int64_t* suffix_offs,
+                       const uint8_t* signal, const int64_t* signal_offs, int32_t n_records, int32_t method, int32_t level,
+                       int32_t threads, uint8_t* out, int64_t capacity);
 
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): 48 per-phase wave-cycle sums since the
  * last call (0-15 decoder, 16-31 the encoder blocks of the frontend, 32-47 the frontend's own

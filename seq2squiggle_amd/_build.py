@@ -3,13 +3,15 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "s2s_hip.hip")
+SRC = os.path.join(HERE, "csrc", "s2s_hip.hip")              # kernels + the C ABI of the GPU path
+SRC_HOST = os.path.join(HERE, "csrc", "s2s_host.cpp")       # host-only helpers (record framing / compression threads)
 
 
 def deps():
-    """Every file the library is compiled from: csrc/*.hip, csrc/*.h, include/*.h."""
+    """Every file the library is compiled from: csrc/*.hip, csrc/*.cpp, csrc/*.h, include/*.h."""
     import glob
-    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.h")) +
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.cpp")) +
+                  glob.glob(os.path.join(HERE, "csrc", "*.h")) +
                   glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
 
 LIB = os.path.join(HERE, "lib", "libs2s_hip.so")
@@ -27,7 +29,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB, SRC, SRC_HOST,
+           "-lz", "-ldl", "-lpthread"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)

@@ -1021,11 +1021,20 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipMalloc(&h->d_arena, h->arena_floats * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(arena)");
     if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(arena)");
-    h->tile = 32768;
     if (const char* tl = getenv("S2S_TWO_LAUNCH")) h->two_launch = tl[0] == '1';
+    // chunks per launch: the fused kernel needs no per-chunk workspace, so a launch is as long as 32-bit chunk indices allow
+    // comfortably (every launch ends in a tail of up to one chunk time per workgroup)
+    h->tile = h->two_launch ? 32768 : (1 << 20);
     {
         const size_t slots = h->two_launch ? (size_t)h->tile : (size_t)h->n_wg * S2S_MAX_GROUP;
         if ((e = hipMalloc(&h->handoff, slots * S2S_SLOT_FLOATS * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(handoff)");
+    }
+    {   // export scratch for the streaming path's usual super-batch, so that its first s2s_export_reads does not have to
+        // drain the stream in order to grow it
+        const int cap = 2 * 32768 + 1;
+        if ((e = hipMalloc(&h->ws_counts, (size_t)cap * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(export counts)");
+        if ((e = hipMalloc(&h->ws_offs, (size_t)cap * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc(export offsets)");
+        h->ws_export_cap = cap;
     }
     const struct { const void* fn; int bytes; } dyn_lds[] = {
         {reinterpret_cast<const void*>(s2s_decoder_kernel<0>), DEC_LDS_F32}, {reinterpret_cast<const void*>(s2s_decoder_kernel<1>), DEC_LDS_H},

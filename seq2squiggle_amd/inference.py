@@ -77,7 +77,38 @@ def iter_batches(reads: Iterable[Tuple[str, str]], k: int, batch_size: int, devi
         yield tuple(ids), torch.from_numpy(np.concatenate(parts)).to(device), torch.from_numpy(np.concatenate(nvs)).to(device)
 
 
+class _Staging:
+    """One super-batch's inputs, host -> device: the arrays are laid back to back in a persistent pinned buffer (pinning is
+    paid once, not per batch -- a fresh pinned allocation costs tens of milliseconds) and go up as ONE copy on the upload
+    stream, so the calling thread never waits for the compute stream the way a pageable copy does."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host = None
+
+    def upload(self, arrays, stream):
+        offs, total = [], 0
+        for a in arrays:
+            offs.append(total)
+            total += -(-a.nbytes // 16) * 16
+        if self.host is None or self.host.numel() < total:
+            self.host = torch.empty(max(total + total // 4, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        hv = self.host.numpy()
+        for a, o in zip(arrays, offs):
+            hv[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            d = self.host[:total].to(self.device, non_blocking=True)
+            up = torch.cuda.Event()
+            up.record(stream)
+        main.wait_event(up)
+        d.record_stream(main)
+        return [d[o:o + a.nbytes].view(torch.from_numpy(a[:0]).dtype) for a, o in zip(arrays, offs)]
+
+
+_STAGING = {}             # device -> the two pinned staging buffers, kept for the life of the process
 _IO = None
+_TRACE = None             # tools/e2e_timeline.py points this at a list to receive run_streaming's event times
 
 
 def _io_executor():
@@ -92,7 +123,7 @@ def _io_executor():
 
 
 def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
-                  max_chunks: int = 32768) -> int:
+                  max_chunks: int = 32768, trace: list = None) -> int:
     """The predict loop without per-chunk Python objects: whole reads are grouped into super-batches of about
     `max_chunks` chunks; per super-batch one H2D of the packed read bytes, s2s_predict_packed, s2s_export_reads
     (zero-strip + int16 conversion on the GPU), one D2H of the packed int16 samples on a copy stream, then the writer.  Produces the
@@ -100,7 +131,13 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
 
     Three stages overlap: while the GPU works on super-batch i the host samples/packs i+1, and a writer thread
     compresses and writes i-1.  Record metadata (the np.random offset draws of signal_io.py:129-132) is built on the
-    calling thread in read order, so the output does not depend on thread timing."""
+    calling thread in read order, so the output does not depend on thread timing.  `trace`: a list that receives
+    (event, seconds) pairs for tools/e2e_timeline.py."""
+    import time
+
+    def mark(ev):
+        if trace is not None:
+            trace.append((ev, time.perf_counter()))
     k = model.config["seq_kmer"]
     dev = model.device
     rna = profile_name.startswith("rna")
@@ -108,23 +145,29 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     io = _io_executor()
     pending = None            # the writer job of the previous super-batch
     inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
-    copy_stream = torch.cuda.Stream(dev)
+    copy_stream = torch.cuda.Stream(dev)      # D2H of finished super-batches
+    up_stream = torch.cuda.Stream(dev)        # H2D of the next one (its own stream: never queued behind a D2H that waits for kernels)
+
+    staging = _STAGING.setdefault(str(dev), (_Staging(dev), _Staging(dev)))   # super-batch i + 2 reuses i's buffer: i has been collected by then
+    n_launched = 0
 
     def launch(group):
-        nonlocal total
+        nonlocal total, n_launched
+        mark("pack")
         flat, chunk_start, n_valid, read_first = pack_reads([s for s, _ in group], k)
         B = int(read_first[-1])
         if B == 0:
             return None
-        out = model.engine.predict_packed(torch.from_numpy(flat).to(dev, non_blocking=True),
-                                          torch.from_numpy(chunk_start).to(dev, non_blocking=True),
-                                          torch.from_numpy(n_valid).to(dev, non_blocking=True), model._params(),
-                                          first_global_chunk=model.chunks_done)
+        mark("h2d+launch")
+        # H2D from pinned staging on the copy stream: a pageable copy on the compute stream would hold this thread until
+        # the previous super-batch's kernels have drained
+        ins = staging[n_launched % 2].upload((flat, chunk_start, n_valid, read_first), up_stream)
+        out = model.engine.predict_packed(ins[0], ins[1], ins[2], model._params(), first_global_chunk=model.chunks_done)
         model.chunks_done += B
         total += B
-        ex = model.engine.export_reads(out["signal"], torch.from_numpy(read_first).to(dev), profile_dict["digitisation"],
-                                       profile_dict["range"], profile_dict["offset_mean"], rna=rna, want_pa=False,
-                                       want_dac=True)
+        n_launched += 1
+        ex = model.engine.export_reads(out["signal"], ins[3], profile_dict["digitisation"], profile_dict["range"],
+                                       profile_dict["offset_mean"], rna=rna, want_pa=False, want_dac=True)
         # D2H on its own stream, so that it runs beside the next super-batch's kernels instead of queueing behind them.
         # The whole capacity is copied (its size is known without a sync; 16 MB per 32 k chunks) into pinned memory.
         ready = torch.cuda.Event()
@@ -139,21 +182,32 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             ex["dac"].record_stream(copy_stream)
             done = torch.cuda.Event()
             done.record(copy_stream)
+        mark("launched")
         return [n for _, n in group], offs_h, dac_h, done
 
     def collect(job):
         nonlocal pending
         ids, offs_h, dac_h, done = job
+        mark("wait d2h")
         done.synchronize()
+        mark("records")
         offs = offs_h.numpy()
         dac = dac_h.numpy()[: int(offs[-1])]
         recs = writer.dac_records(ids, dac, offs)
+        mark("wait writer")
         if pending is not None:
             pending.result()
-        pending = io.submit(writer.write_records, recs)
+        mark("submit")
+
+        def job_(recs=recs):
+            mark("writer start")
+            writer.write_records(recs)
+            mark("writer end")
+        pending = io.submit(job_)
 
     try:
         group, n = [], 0
+        mark("first read wanted")
         for seq, name in reads:
             c = _n_chunks(len(seq), k)
             if c == 0:
@@ -179,6 +233,7 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     finally:
         if hasattr(writer, "close"):               # POD5: run-info and reads tables, footer (on the writer thread as well)
             io.submit(writer.close).result()
+        mark("done")
     return total
 
 
@@ -210,40 +265,49 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     if world > 1 and not seed:
         raise ValueError("multi-process runs need one seed for all ranks: pass an explicit --seed, or let the CLI share a "
                          "fresh one (parallel.shared_seed) before calling inference_run")
-    if world > 1 and not read_input:
-        # every rank replays the sampler for the read lengths, then builds only its own contiguous share of the reads
-        from .utils import preprocess_genome, sample_read_shard
-        genome_seqs, genome_lens = preprocess_genome(fasta)
-        picked = {}
+    # the checkpoint is read and the engine created (weight re-packing, device allocations: native code, no interpreter lock)
+    # on a helper thread while this one parses the FASTA and samples the reads
+    from concurrent.futures import ThreadPoolExecutor
+    loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-load")
+    loading = loader.submit(
+        seq2squiggle.load_from_checkpoint, checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean,
+        dwell_std=dwell_std, noise_std=noise_std, noise_sampling=noise_sampling, duration_sampling=duration_sampling,
+        export_every_n_samples=export_every_n_samples, min_noise=min_noise, min_duration=min_duration, device=local_rank,
+        mode=mode, seed=seed)
+    try:
+        if world > 1 and not read_input:
+            # every rank replays the sampler for the read lengths, then builds only its own contiguous share of the reads
+            from .utils import preprocess_genome, sample_read_shard
+            genome_seqs, genome_lens = preprocess_genome(fasta)
+            picked = {}
 
-        def shard_of(lens):
-            lo, hi, picked["first"] = shard_reads(lens, config["seq_kmer"], world)[rank]
-            picked["lo"] = lo
-            return lo, hi
-        reads, lens = sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of)
-        first_chunk, first_read = picked["first"], picked["lo"]
-        logger.info(f"rank {rank}/{world}: {len(reads)} of {len(lens)} reads, first global chunk {first_chunk}")
-    else:
-        reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
-        if world > 1:                  # read mode: every rank parses the same file, then keeps its contiguous share
-            reads = list(reads)
-            lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
-            reads = reads[lo:hi]
-            first_read = lo
-            logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
+            def shard_of(lens):
+                lo, hi, picked["first"] = shard_reads(lens, config["seq_kmer"], world)[rank]
+                picked["lo"] = lo
+                return lo, hi
+            reads, lens = sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of)
+            first_chunk, first_read = picked["first"], picked["lo"]
+            logger.info(f"rank {rank}/{world}: {len(reads)} of {len(lens)} reads, first global chunk {first_chunk}")
+        else:
+            reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
+            if world > 1:                  # read mode: every rank parses the same file, then keeps its contiguous share
+                reads = list(reads)
+                lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
+                reads = reads[lo:hi]
+                first_read = lo
+                logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
+    finally:
+        loader.shutdown(wait=True)
 
     if first_read:
         writer.start_at(first_read)            # read ids / read_number / record draws continue the single-process run
-    load_model = seq2squiggle.load_from_checkpoint(
-        checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean, dwell_std=dwell_std, noise_std=noise_std,
-        noise_sampling=noise_sampling, duration_sampling=duration_sampling, export_every_n_samples=export_every_n_samples,
-        min_noise=min_noise, min_duration=min_duration, device=local_rank, mode=mode, seed=seed,
-        first_global_chunk=first_chunk)
+    load_model = loading.result()
+    load_model.chunks_done = int(first_chunk)  # global chunk index of this rank's first chunk: keys the device RNG counters
     check_model(load_model, config)
 
     n_chunks = 0
     if streaming and hasattr(writer, "dac_records"):
-        n_chunks = run_streaming(load_model, reads, writer, profile_dict, profile)
+        n_chunks = run_streaming(load_model, reads, writer, profile_dict, profile, trace=_TRACE)
     else:
         for batch in iter_batches(reads, config["seq_kmer"], predict_batch_size, load_model.device):
             load_model.predict_step(batch)

@@ -110,8 +110,8 @@ class BLOW5Writer:
         self.start_time = 0
         self.n_written = 0
         self.binary = self.filename.endswith(".blow5")
-        self.compress_level = 1               # zlib level of BLOW5 records; any level is a valid zlib stream
-        self._pool = None
+        self.compress_level = 1               # zlib / zstd level of BLOW5 records; any level is a valid stream
+        self.threads = min(64, len(os.sched_getaffinity(0)))    # compression threads (the reference: cpu_count)
 
     def start_at(self, read_index: int) -> None:
         """Rank shards (parallel.py): this writer's first read is read `read_index` of the whole job, so read ids and
@@ -217,31 +217,73 @@ class BLOW5Writer:
     # BLOW5 v0.2.0: 64-byte file header, u32 size + ASCII header, records (u64 size + zlib stream), "5WOLB"
     _EOF = b"5WOLB"
 
-    def _blow5_record(self, r) -> bytes:
-        """u64 size + the (record-compressed) body.  Body: read_id_len u16, read_id, read_group u32, digitisation, offset,
-        range, sampling_rate f64, len_raw_signal u64, raw_signal, then the auxiliary fields in header order.
-        With signal method svb-zd the raw_signal bytes are the codec's blob (u32 sample count + StreamVByte stream) and --
-        as remembered from slow5lib's slow5_rec_to_mem / slow5_rec_parse, NOT verified against the library -- the
-        len_raw_signal field then carries the blob's byte length (the parser needs it to find the auxiliary fields; the
-        sample count is inside the blob)."""
+    def _record_fields(self, r):
+        """(bytes before raw_signal, signal bytes or array, bytes after it) of one record body: read_id_len u16, read_id,
+        read_group u32, digitisation, offset, range, sampling_rate f64, len_raw_signal u64 | raw_signal | the auxiliary
+        fields in header order.  With signal method svb-zd the raw_signal bytes are the codec's blob (u32 sample count +
+        StreamVByte stream) and -- as remembered from slow5lib's slow5_rec_to_mem / slow5_rec_parse, NOT verified against the
+        library -- the len_raw_signal field then carries the blob's byte length (the parser needs it to find the auxiliary
+        fields; the sample count is inside the blob)."""
         rid, ch = r["read_id"].encode(), r["channel_number"].encode()
-        raw = np.ascontiguousarray(r["signal"]).astype("<i2")
         if self.signal_compression == "svb-zd":
             from .codecs import svb_zd_compress
-            sig = r.get("svb") or svb_zd_compress(raw)
-            n_field = len(sig)
+            sig = r.get("svb") or svb_zd_compress(np.ascontiguousarray(r["signal"]).astype("<i2"))
+            sig = np.frombuffer(sig, dtype=np.uint8)
+            n_field = sig.size
         else:
-            sig, n_field = raw.tobytes(), r["len_raw_signal"]
-        body = (struct.pack("<H", len(rid)) + rid + struct.pack("<IddddQ", r["read_group"], r["digitisation"], r["offset"],
-                                                                 r["range"], r["sampling_rate"], n_field)
-                + sig + struct.pack("<H", len(ch)) + ch
+            sig = np.ascontiguousarray(r["signal"]).astype("<i2", copy=False).view(np.uint8)
+            n_field = r["len_raw_signal"]
+        head = (struct.pack("<H", len(rid)) + rid
+                + struct.pack("<IddddQ", r["read_group"], r["digitisation"], r["offset"], r["range"], r["sampling_rate"], n_field))
+        tail = (struct.pack("<H", len(ch)) + ch
                 + struct.pack("<diBQ", r["median_before"], r["read_number"], r["start_mux"], r["start_time"]))
+        return head, sig, tail
+
+    def _blow5_record(self, r) -> bytes:
+        """u64 size + the (record-compressed) body of ONE record, in Python (tests pin _pack_native against it)."""
+        head, sig, tail = self._record_fields(r)
+        body = head + sig.tobytes() + tail
         if self.record_compression == "zlib":
             body = zlib.compress(body, self.compress_level)
         elif self.record_compression == "zstd":
             from .codecs import zstd_compress
             body = zstd_compress(body, 1)
         return struct.pack("<Q", len(body)) + body
+
+    def _pack_native(self, recs) -> memoryview:
+        """All records of a batch, framed and compressed by s2s_blow5_pack (libs2s_hip.so, host threads)."""
+        import ctypes as C
+        from ._lib import lib
+        fields = [self._record_fields(r) for r in recs]
+        n = len(fields)
+
+        def flat(parts):
+            offs = np.zeros(n + 1, np.int64)
+            np.cumsum([len(p) for p in parts], out=offs[1:])
+            return np.frombuffer(b"".join(parts), dtype=np.uint8) if offs[-1] else np.zeros(1, np.uint8), offs
+        head, head_offs = flat([f[0] for f in fields])
+        tail, tail_offs = flat([f[2] for f in fields])
+        sigs = [f[1] for f in fields]
+        sig_offs = np.zeros(n + 1, np.int64)
+        np.cumsum([s_.size for s_ in sigs], out=sig_offs[1:])
+        # the records of a super-batch are consecutive slices of one packed array (run_streaming): no copy then
+        base = sigs[0].base if sigs[0].base is not None else sigs[0]
+        first = sigs[0].__array_interface__["data"][0]
+        contiguous = all(s_.__array_interface__["data"][0] == first + int(sig_offs[i]) for i, s_ in enumerate(sigs))
+        sig = np.concatenate(sigs) if not contiguous else None
+        sig_ptr = sig.ctypes.data if sig is not None else first
+        total = int(head_offs[-1] + tail_offs[-1] + sig_offs[-1])
+        L = lib()
+        cap = int(L.s2s_blow5_pack_bound(total, n))
+        out = np.empty(cap, np.uint8)
+        threads = min(self.threads, max(1, n))
+        got = L.s2s_blow5_pack(head.ctypes.data, head_offs.ctypes.data, tail.ctypes.data, tail_offs.ctypes.data, C.c_void_p(sig_ptr),
+                               sig_offs.ctypes.data, n, self.RECORD_METHODS[self.record_compression], self.compress_level,
+                               threads, out.ctypes.data, cap)
+        del base
+        if got < 0:
+            raise RuntimeError(f"s2s_blow5_pack failed ({got})")
+        return memoryview(out)[:got]
 
     def _save_blow5(self, append: bool, recs):
         if append:
@@ -257,13 +299,11 @@ class BLOW5Writer:
                       + struct.pack("<I", 1) + bytes([self.SIGNAL_METHODS[self.signal_compression]]))
                 f.write(fh + bytes(64 - len(fh)))
                 f.write(struct.pack("<I", len(hdr)) + hdr)
-            # zlib releases the GIL: compress records on worker threads, write in order
+            # framing + compression on native worker threads (s2s_blow5_pack), one write per batch
             # (the reference: write_record_batch(threads=cpu_count), signal_io.py:167-171)
-            if self._pool is None:                     # kept for the writer's lifetime: one save per super-batch
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1))
-            for blob in self._pool.map(self._blow5_record, recs):
-                f.write(blob)
+            recs = recs if isinstance(recs, list) else list(recs)
+            if recs:
+                f.write(self._pack_native(recs))
             f.write(self._EOF)
 
 

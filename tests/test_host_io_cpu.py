@@ -212,6 +212,41 @@ def test_blow5_compression_methods(tmp_path, rec, sig):
                               record_compression="lzma")
 
 
+@pytest.mark.parametrize("rec", ["none", "zlib", "zstd"])
+def test_native_record_packer_equals_the_python_framing(tmp_path, rec):
+    """s2s_blow5_pack (host threads inside libs2s_hip.so) against _blow5_record, record by record after decompression:
+    ragged sizes incl. a one-sample read, more threads than records and fewer, signals that are and are not slices of one
+    packed array, and a second call on the same (persistent) thread pool."""
+    import struct, zlib
+    from seq2squiggle_amd import codecs
+    rng = np.random.default_rng(5)
+    prof = U.get_profile("dna-r9-min")
+
+    def unpack(buf):
+        out, pos = [], 0
+        while pos < len(buf):
+            n = struct.unpack_from("<Q", buf, pos)[0]
+            body = bytes(buf[pos + 8: pos + 8 + n])
+            out.append(zlib.decompress(body) if rec == "zlib" else
+                       codecs.zstd_decompress(body, codecs.zstd_frame_content_size(body)) if rec == "zstd" else body)
+            pos += 8 + n
+        return out
+    for n_reads, threads in ((1, 4), (7, 2), (150, 64), (150, 3)):
+        w = signal_io.BLOW5Writer(str(tmp_path / "p.blow5"), prof, False, "dna-r9-min", False, record_compression=rec)
+        w.threads = threads
+        lens = rng.integers(1, 40000, n_reads)
+        lens[0] = 1
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        dac = np.cumsum(rng.integers(-40, 41, int(offs[-1]))).astype(np.int16)
+        np.random.seed(3)
+        recs = w.dac_records([f"read{i}" for i in range(n_reads)], dac, offs)
+        want = [w._blow5_record(r) for r in recs]
+        got = unpack(w._pack_native(recs))
+        assert got == unpack(b"".join(want))
+        scattered = [dict(r, signal=r["signal"].copy()) for r in recs]      # not slices of one array any more
+        assert unpack(w._pack_native(scattered)) == got
+
+
 def test_onehot_to_bases_equals_chunker():
     from seq2squiggle_amd.model import onehot_to_bases
     lut = np.full(256, 255, np.uint8)

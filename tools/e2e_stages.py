@@ -27,7 +27,7 @@ def run(out):
     return c
 
 
-with tempfile.TemporaryDirectory() as td:
+with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
     run(os.path.join(td, f"warm.{ext}"))
     t0 = time.perf_counter()
     chunks = run(os.path.join(td, f"a.{ext}"))
