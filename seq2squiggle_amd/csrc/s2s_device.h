@@ -67,6 +67,10 @@ struct DebugDev {
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Output streams (signal, dwell counts) are stored past the XCD's L2 (global_store ... sc1: the line is not kept), so that they
+// do not push the frontend -> decoder hand-off slots and the weights out of it.
+__device__ __forceinline__ void store_stream(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_stream(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Reductions over the 4 lane groups (lanes c, c+16, c+32, c+48) with the gfx950 row/half swaps
 // (v_permlane16_swap: odd rows of a <-> even rows of b; v_permlane32_swap: upper half of a <-> lower
 // half of b): pure VALU, no LDS round trip.

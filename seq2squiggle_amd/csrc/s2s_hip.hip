@@ -173,33 +173,16 @@ __device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* 
                 for (int ft = 0; ft < 4; ++ft)
                     *reinterpret_cast<f32x4*>(dbg.emb_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = S[q][ft];
     }
-    DIAG_STAMP(1);
-#pragma unroll 1
-    for (int l = 0; l < M.enc_layers; ++l) {
-        if constexpr (MODE == 1) fft_block_h<NQ, 1, 1, 16, true, (NQ > 1)>(W, M.enc[l], X, lds_raw, 0, 0, lane, one, diag_blk);
-        else                     fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane, diag_blk);
-    }
-    DIAG_STAMP(2);
     HL Sb[NQ][2];                                                    // emb_out as a B operand for the three heads
     if (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { Sb[q][0] = split8(S[q][0], S[q][1], one); Sb[q][1] = split8(S[q][2], S[q][3], one); }
     }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (!io[q].live) continue;
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(io[q].slot + c * 64 + 16 * ft + 4 * g) = X[q][ft];
-        if (dbg.enc_out) {
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
-                *reinterpret_cast<f32x4*>(dbg.enc_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = X[q][ft];
-        }
-    }
-
-    // ---- NoiseSampler (modules.py:275-278).  Every lane group holds the heads' values of all tiles (sum_g is an all-reduce),
-    //      so from here on lane group q finishes chunk q: ONE pass of the dwell sampler per wave.
-    DIAG_STAMP(3);
+    // ---- the three heads read emb_out only (modules.py:275-278, 197-225), so they run BEFORE the encoder blocks: emb_out is
+    //      dead by then instead of being carried (and spilled) through them.
+    //      NoiseSampler: every lane group holds the heads' values of all tiles (sum_g is an all-reduce), so lane group q
+    //      finishes chunk q: ONE pass of the dwell sampler per wave.
+    DIAG_STAMP(1);
     float sig[NQ];
     mlp_head<MODE, NQ>(W, M.noise, S, Sb, lane, sig);
     float sigma = sig[0];
@@ -254,10 +237,29 @@ __device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* 
     if (mine) {
         const float rd = fminf(fmaxf(rintf(gv), -1.0e9f), 1.0e9f);  // torch.round: half-to-even (modules.py:437)
         reinterpret_cast<int*>(me.slot + 1040)[c] = (int)rd;
-        me.out_dur[c] = (int)rd;
+        store_stream(me.out_dur + c, (int)rd);
         if (dbg.g) dbg.g[me.dbg_idx * 16 + c] = gv;
     }
     DIAG_STAMP(5);
+#pragma unroll 1
+    for (int l = 0; l < M.enc_layers; ++l) {
+        if constexpr (MODE == 1) fft_block_h<NQ, 1, 1, 16, true, (NQ > 1)>(W, M.enc[l], X, lds_raw, 0, 0, lane, one, diag_blk);
+        else                     fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane, diag_blk);
+    }
+    DIAG_STAMP(2);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!io[q].live) continue;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(io[q].slot + c * 64 + 16 * ft + 4 * g) = X[q][ft];
+        if (dbg.enc_out) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                *reinterpret_cast<f32x4*>(dbg.enc_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = X[q][ft];
+        }
+    }
+
+    DIAG_STAMP(3);
 }
 
 // two-launch path: one wave per chunk, enc_out / sigma / dur handed to the decoder kernel through the handle's workspace
@@ -407,7 +409,7 @@ __device__ __forceinline__ void dec_emit(const ModelDev& M, const float ys, cons
                                  : P.noise_std;
             if (y != 0.0f) y = mul_then_add(z, sd, y);
         }
-        out_signal[t] = fmaxf(y, 0.0f);
+        store_stream(out_signal + t, fmaxf(y, 0.0f));
     }
 }
 
@@ -503,7 +505,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
                                    inj_zdw ? inj_zdw + (size_t)b * 16 : nullptr, slot0 + j * S2S_SLOT_FLOATS,
                                    out_dur + (size_t)b * 16, dbg_base + b, live};
             }
-            frontend_chunks<F::FMODE, F::FNQ>(M, W, io, P, lds_raw + wave * FrontLds<F::FMODE, F::FNQ>::BYTES, dbg, lane, one);
+            int lnf = lane;                // (opaque per group, like `ln` below: nothing lane-dependent is hoisted out of the loops and spilled)
+            asm volatile("" : "+v"(lnf));
+            frontend_chunks<F::FMODE, F::FNQ>(M, W, io, P, lds_raw + wave * FrontLds<F::FMODE, F::FNQ>::BYTES, dbg, lnf, one);
         }
         __syncthreads();                   // the group's slots are written (global stores: workgroup-scope release/acquire)
         DIAG_STAMP(7);                     // frontend phase and its two barriers

@@ -1,13 +1,15 @@
 #!/usr/bin/env python
 """Condense the rocprofv3 --pmc passes written by tools/pmc_run.sh into one JSON:
-python tools/pmc_summarize.py mode=dir [mode=dir ...] > profiles/rNN/pmc_summary.json
-For every kernel the counters of its FIRST dispatch in each pass (a full 32,768-chunk decoder launch for the bench
-workload); Grid_Size / Workgroup_Size / Scratch_Size / VGPR_Count are kept so the launch can be identified."""
+python tools/pmc_summarize.py mode=dir[:chunks] [mode=dir[:chunks] ...] > profiles/rNN/pmc_summary.json
+For every kernel the counters of its FIRST dispatch in each pass (tools/pmc_run.sh: bench.py --reads 210 = one launch of
+65,520 chunks; pass that count as :chunks so that bench.py can scale the counters per chunk); Grid_Size / Workgroup_Size /
+Scratch_Size / VGPR_Count are kept so the launch can be identified."""
 import csv, glob, json, os, sys
 
 out = {}
 for arg in sys.argv[1:]:
     mode, d = arg.split("=", 1)
+    d, _, chunks = d.partition(":")
     per = {}
     for path in sorted(glob.glob(os.path.join(d, "pmc*_counter_collection.csv"))):
         seen = {}
@@ -20,6 +22,6 @@ for arg in sys.argv[1:]:
             k[row["Counter_Name"]] = float(row["Counter_Value"])
             k.setdefault("_launch", {"grid": int(row["Grid_Size"]), "workgroup": int(row["Workgroup_Size"]),
                                      "scratch_bytes_per_lane": int(row["Scratch_Size"]), "vgprs": int(row["VGPR_Count"]),
-                                     "lds_bytes": int(row["LDS_Block_Size"])})
+                                     "lds_bytes": int(row["LDS_Block_Size"]), **({"chunks": int(chunks)} if chunks else {})})
     out[mode] = per
 json.dump(out, sys.stdout, indent=1)

@@ -12,5 +12,5 @@ for m in f16x3 f32; do
   bash $R/tools/pmc_run.sh $T/pmc_$m --mode $m
 done
 cd $R && python3 bench.py > gpurun_out/$T/bench_f16x3.json 2> gpurun_out/$T/bench_f16x3.err
-python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32 f16x3=gpurun_out/$T/pmc_f16x3 > gpurun_out/$T/pmc_summary.json
+python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32:65520 f16x3=gpurun_out/$T/pmc_f16x3:65520 > gpurun_out/$T/pmc_summary.json
 ls gpurun_out/$T gpurun_out/$T/stats_f16x3
