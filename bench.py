@@ -31,10 +31,8 @@ sys.path.insert(0, ROOT)
 import seq2squiggle_amd as S  # noqa: E402
 
 FLOP_PER_CHUNK = 85_083_392            # 2 x 42,541,696 MAC, k = 9
-FLOP_PER_CHUNK_DECODER = 2 * 40_592_000   # decoder-side share, SURVEY.md section 2.2 (the two-launch A/B path times it alone)
-TWO_LAUNCH = os.environ.get("S2S_TWO_LAUNCH", "0")[:1] == "1"      # the library reads the same variable at s2s_create
-FLOP_PER_CHUNK_DOMINANT = FLOP_PER_CHUNK_DECODER if TWO_LAUNCH else FLOP_PER_CHUNK
-DOMINANT_KERNEL = "s2s_decoder_kernel" if TWO_LAUNCH else "s2s_fused_kernel"
+FLOP_PER_CHUNK_DOMINANT = FLOP_PER_CHUNK  # the one kernel of the path does all of it (of which 81,184,000 decoder-side)
+DOMINANT_KERNEL = "s2s_fused_kernel"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 # roofline.frac is always quoted against the guide's dense peak of the MFMA dtype the mode issues.  (f16x3 evaluates every
@@ -61,7 +59,7 @@ def pmc_counters(mode, chunks_per_launch):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(path)).get(mode, {})
-            k = next(k for k in d if ("decoder" if TWO_LAUNCH else "fused") in k)
+            k = next(k for k in d if "fused" in k)
             c = d[k]
             chunks = c.get("_launch", {}).get("chunks", 32768)
             per_chunk = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / chunks

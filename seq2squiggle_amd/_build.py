@@ -24,17 +24,22 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+def compile_to(out: str, extra=(), verbose: bool = False) -> str:
+    """hipcc -> `out` with extra flags (tools build -D variants of the library this way)."""
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB, SRC, SRC_HOST,
-           "-lz", "-ldl", "-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", *extra, "-o", out,
+           SRC, SRC_HOST, "-lz", "-ldl", "-lpthread"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    return compile_to(LIB, verbose=verbose)
 
 
 if __name__ == "__main__":

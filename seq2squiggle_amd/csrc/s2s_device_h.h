@@ -32,6 +32,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_FFN_LDS
 #define S2S_FFN_LDS 1           // decoder FFN weights staged once per workgroup in the dead K/V region (0: every wave streams them from L2)
 #endif
+#define S2S_PF_FLOATS (1024 + 16 + 16)   // one frontend -> decoder hand-off slot (s2s_hip.hip: S2S_SLOT_FLOATS)
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
 // Scheduling barriers pin the weight-unit / K,V-fragment loads in front of the MFMAs they are prefetched behind; the
 // -DS2S_NO_SB_* builds measure what they are worth (the one in the attention pass: 15 % of the kernel).
@@ -320,7 +321,8 @@ __device__ __forceinline__ void load_unit_h(f32x4 (&f)[4], const float* __restri
 template <int NQ, int WAVES, int NKT, int TV, bool LO = true, bool SEP = false>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
-                                            unsigned long long* diag_buf = nullptr) {
+                                            unsigned long long* diag_buf = nullptr, const float* __restrict__ pf_src = nullptr,
+                                            float* __restrict__ pf_dst = nullptr) {
     using G = AttnLdsH<NQ, WAVES, NKT, SEP>;
     static_assert(!SEP || (WAVES == 1 && NKT == 1), "SEP: every time tile is a one-tile sequence owned by this wave");
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
@@ -531,9 +533,16 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             gm[ft] = ldg4(W + L.ln1g + 16 * ft + 4 * g); bt[ft] = ldg4(W + L.ln1b + 16 * ft + 4 * g);
             b2v[ft] = ldg4(W + L.b2 + 16 * ft + 4 * g);
         }
+        // piggy-back (the decoder's last layer): PF_FLOATS floats from pf_src -> LDS at pf_dst, visible to every wave after
+        // the second barrier below like the weights themselves
+        constexpr int PF_VEC = S2S_PF_FLOATS / 4;
+        const int pf_i = wave * 64 + lane;
+        f32x4 pfv = f32x4{0, 0, 0, 0};
+        if (pf_src && pf_i < PF_VEC) pfv = ldg4(pf_src + 4 * pf_i);
         DIAG_STAMP(3);
         __syncthreads();                                             // every wave is done reading K/V
         DIAG_STAMP(12);
+        if (pf_src && pf_i < PF_VEC) *reinterpret_cast<f32x4*>(pf_dst + 4 * pf_i) = pfv;
         float* wst = reinterpret_cast<float*>(lds) + lane * 4;
 #pragma unroll
         for (int hc = 0; hc < 4; ++hc)

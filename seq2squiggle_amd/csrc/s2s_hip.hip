@@ -1,13 +1,13 @@
 // s2s_hip.hip -- kernels and C ABI (include/s2s_hip.h) of the MI355X-native seq2squiggle
 // predict path.  gfx950 only; no fallbacks.
 //
-// Two launches per tile of chunks:
-//   s2s_frontend_kernel  one wave per chunk: k-mer embedding gather, pre-net, encoder FFT blocks,
-//                        noise / duration heads, Philox Gamma or Normal dwell -> enc_out, sigma, dur
-//   s2s_decoder_kernel   one 8-wave workgroup per chunk: length-regulator gather + positional
-//                        add, decoder FFT blocks (T = 250 padded to 256; 32 time columns per
-//                        wave), output projection, x165, Philox noise, clamp -> signal[250]
-// plus s2s_export_* for the per-read zero-strip / int16 conversion.
+// One launch per tile of chunks, s2s_fused_kernel: persistent 8-wave workgroups, each walking its share of the chunks in
+// groups of 16:
+//   frontend   wave w, two chunks at a time: k-mer embedding gather, pre-net, the noise / duration heads, Philox Gamma or
+//              Normal dwell, encoder FFT blocks -> enc_out, sigma, dur in the workgroup's L2-resident hand-off slots
+//   decoder    all 8 waves, one chunk after the other: length-regulator gather + positional add, decoder FFT blocks
+//              (T = 250 padded to 256; 32 time columns per wave), output projection, x165, Philox noise, clamp -> signal[250]
+// plus s2s_export_* for the per-read zero-strip / int16 conversion and s2s_svb_* for the containers' signal codecs.
 #include "s2s_device.h"
 #include "s2s_device_h.h"
 #include "../../include/s2s_hip.h"
@@ -85,7 +85,7 @@ struct FrontChunk {
     long long dbg_idx;
     bool live;
 };
-#define S2S_SLOT_FLOATS (1024 + 16 + 16)
+#define S2S_SLOT_FLOATS S2S_PF_FLOATS
 
 // The frontend of NQ chunks, run by ONE wave (T = 16: every chunk is a single time tile and a sequence of its own): embedding,
 // pre-net, encoder blocks, the three heads and the dwell source.  `lds_raw`: FrontLds<MODE, NQ>::BYTES owned by this wave.
@@ -262,25 +262,6 @@ __device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* 
     DIAG_STAMP(3);
 }
 
-// two-launch path: one wave per chunk, enc_out / sigma / dur handed to the decoder kernel through the handle's workspace
-template <int MODE>
-__global__ __launch_bounds__(64) void s2s_frontend_kernel(
-    const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
-    const long long* __restrict__ chunk_start, const uint8_t* __restrict__ n_valid, long long first_chunk, ParamsDev P,
-    const float* __restrict__ inj_g, const float* __restrict__ inj_zdw, float* __restrict__ ws_slots,
-    int* __restrict__ out_dur, DebugDev dbg, long long dbg_base) {
-    __shared__ __attribute__((aligned(16))) char lds_raw[FrontLds<MODE, 1>::BYTES];
-    float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
-    asm volatile("" : "+s"(one));
-    const int b = blockIdx.x, nb = S2S_T_ENC + M.k - 1;
-    // chunk b's 16+k-1 bytes: a row of the dense [B][16+k-1] array, or a window of the packed read buffer
-    const FrontChunk io[1] = {{chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb, n_valid[b],
-                               (unsigned long long)(first_chunk + b), inj_g ? inj_g + b * 16 : nullptr,
-                               inj_zdw ? inj_zdw + b * 16 : nullptr, ws_slots + (size_t)b * S2S_SLOT_FLOATS, out_dur + b * 16,
-                               dbg_base + b, true}};
-    frontend_chunks<MODE, 1>(M, W, io, P, lds_raw, dbg, threadIdx.x, one);
-}
-
 // ================================================================================ decoder
 #ifndef DEC_WAVES
 #define DEC_WAVES 8
@@ -349,14 +330,19 @@ __device__ __forceinline__ void dec_gather_finish(const GatherRaw& R, const int 
     }
 }
 
+// next_slot (MODE 1 only): the NEXT chunk's hand-off slot, copied into the LDS words behind the block's own image by the last
+// layer's FFN weight staging step (one more load per lane before its barrier, one more LDS store after it), so that the gather
+// that follows this chunk reads LDS instead of paying two dependent L2 round trips.
 template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h), 3: the same block with single f16 products
 __device__ __forceinline__ void dec_blocks(const ModelDev& M, const float* __restrict__ W, f32x4 (&X)[DEC_NQ][4],
                                            char* __restrict__ lds_raw, const int wave, const int lane, const float one,
-                                           unsigned long long* diag) {
+                                           unsigned long long* diag, const float* __restrict__ next_slot = nullptr) {
     const int qt0 = DEC_NQ * wave;
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
-        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag);
+        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
+                                                                          l == M.dec_layers - 1 ? next_slot : nullptr,
+                                                                          reinterpret_cast<float*>(lds_raw + DEC_LDS_H));
         else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag);
         else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, reinterpret_cast<float*>(lds_raw), qt0, lane, diag);
     }
@@ -413,42 +399,7 @@ __device__ __forceinline__ void dec_emit(const ModelDev& M, const float ys, cons
     }
 }
 
-// two-launch path: persistent workgroups (LDS allows one per CU), each walks the chunk list with stride gridDim.x, so a CU
-// never waits for a workgroup to drain, be re-dispatched and re-allocate 148 KB of LDS between chunks
-template <int MODE>
-__global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_decoder_kernel(
-    const ModelDev M, const float* __restrict__ W, const float* __restrict__ ws_slots, int n_chunks, long long first_chunk,
-    ParamsDev P, const float* __restrict__ inj_z01, float* __restrict__ out_signal, DebugDev dbg, long long dbg_base) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-#pragma unroll 1
-    for (int b = blockIdx.x; b < n_chunks; b += gridDim.x) {
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63;
-        float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
-        asm volatile("" : "+s"(one));
-        const float* slot = ws_slots + (size_t)b * S2S_SLOT_FLOATS;
-#ifdef S2S_DIAG
-        unsigned long long* diag_buf = dbg.diag;
-#endif
-        DIAG_DECL;
-        f32x4 X[DEC_NQ][4];
-        float sig_ext[DEC_NQ], ys, se;
-        {
-            GatherRaw R;
-            dec_gather_issue(M, W, slot, wave, lane, R);
-            dec_gather_finish(R, wave, lane, X, sig_ext);
-        }
-        DIAG_STAMP(8);
-        dec_blocks<MODE>(M, W, X, lds_raw, wave, lane, one, dbg.diag);
-        DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
-        dec_project(M, W, X, sig_ext, lane, ys, se);
-        dec_emit(M, ys, se, (unsigned long long)(first_chunk + b), P, inj_z01 ? inj_z01 + (size_t)b * S2S_T_DEC : nullptr,
-                 out_signal + (size_t)b * S2S_T_DEC, dbg, dbg_base + b, wave, lane);
-        DIAG_STAMP(9);
-    }
-}
-
-// Fused path (default): ONE launch per tile of chunks, nothing but the bases comes in and nothing but dwell counts and
+// ONE launch per tile of chunks, nothing but the bases comes in and nothing but dwell counts and
 // signal goes out.  A persistent 8-wave workgroup owns a contiguous range of the tile's chunks and walks it in groups of up
 // to 8 * FNQ: wave w runs the one-wave frontend of chunks FNQ*w .. FNQ*w+FNQ-1 of the group (their encoder K/V in a slice of
 // the decoder's K/V region, dead between chunks), then all 8 waves decode the group's chunks one after the other.  The
@@ -458,7 +409,9 @@ template <int MODE> struct Fused {
     static constexpr int FMODE = (MODE == 3) ? 1 : MODE;          // the reduced-precision decoder keeps the f16x3 frontend
     static constexpr int FNQ = (FMODE == 1) ? 2 : 1;              // chunks per frontend wave
     static constexpr int GROUP = DEC_WAVES * FNQ;
-    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H;
+    static constexpr bool PF = (MODE == 1);                       // next chunk's slot prefetched into LDS (dec_blocks)
+    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (PF ? S2S_SLOT_FLOATS * 4 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS per workgroup");
     static_assert(DEC_WAVES * FrontLds<FMODE, FNQ>::BYTES <= LDS, "the frontend waves' K/V images share the decoder's LDS");
 };
 #define S2S_MAX_GROUP (2 * DEC_WAVES)
@@ -522,7 +475,10 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
 #pragma unroll 1
         for (int j = 0; j < n_here; ++j) {
             const int b = g0 + j;
-            dec_blocks<MODE>(M, W, X, lds_raw, wave, lane, one, dbg.diag);
+            // (after the group's last chunk everything "next" is that chunk again, computed and thrown away: no branches here,
+            // the register allocator spills values that live from one conditional block to another)
+            const float* next = slot0 + (j + 1 < n_here ? j + 1 : j) * S2S_SLOT_FLOATS;
+            dec_blocks<MODE>(M, W, X, lds_raw, wave, lane, one, dbg.diag, F::PF ? next : nullptr);
             DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
             // (an opaque copy of the lane id: the per-lane addresses below are recomputed per chunk, a handful of VALU
             // instructions, instead of being hoisted out of the loop and spilled across the blocks -- a scratch reload here
@@ -531,10 +487,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
             asm volatile("" : "+v"(ln));
             float ys, se;
             dec_project(M, W, X, sig_ext, ln, ys, se);
-            // the next chunk's rows are requested before this one's noise is drawn: two dependent L2 round trips hide behind
-            // Philox + Box-Muller (after the group's last chunk: the same chunk again, thrown away)
+            // the next chunk's rows are requested before this one's noise is drawn, from the copy of its slot that the last
+            // block left in LDS (f16x3), or from the slot itself: two dependent L2 round trips behind Philox + Box-Muller
             GatherRaw R;
-            dec_gather_issue(M, W, slot0 + (j + 1 < n_here ? j + 1 : j) * S2S_SLOT_FLOATS, wave, ln, R);
+            if constexpr (F::PF) dec_gather_issue(M, W, reinterpret_cast<const float*>(lds_raw + DEC_LDS_H), wave, ln, R);
+            else                 dec_gather_issue(M, W, next, wave, ln, R);
             dec_emit(M, ys, se, (unsigned long long)(first_chunk + b), P, inj_z01 ? inj_z01 + (size_t)b * S2S_T_DEC : nullptr,
                      out_signal + (size_t)b * S2S_T_DEC, dbg, dbg_base + b, wave, ln);
             dec_gather_finish(R, wave, ln, X, sig_ext);
@@ -730,8 +687,7 @@ struct s2s_handle {
     size_t arena_floats = 0;
     int tile = 0;                     // chunks per launch pair
     int n_wg = 256;                   // decoder grid: persistent workgroups, one per CU
-    float* handoff = nullptr;         // frontend -> decoder slots: [n_wg][S2S_MAX_GROUP][S2S_SLOT_FLOATS] (L2-resident), or, with
-    bool two_launch = false;          // S2S_TWO_LAUNCH=1 at creation (the unfused two launches, for A/B measurements): [tile] slots
+    float* handoff = nullptr;         // frontend -> decoder slots: [n_wg][S2S_MAX_GROUP][S2S_SLOT_FLOATS] (L2-resident)
     int* ws_counts = nullptr;         // export scratch, grown on demand outside of launches
     long long* ws_offs = nullptr;
     int ws_export_cap = 0;
@@ -1025,14 +981,11 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipMalloc(&h->d_arena, h->arena_floats * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(arena)");
     if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(arena)");
-    if (const char* tl = getenv("S2S_TWO_LAUNCH")) h->two_launch = tl[0] == '1';
-    // chunks per launch: the fused kernel needs no per-chunk workspace, so a launch is as long as 32-bit chunk indices allow
+    // chunks per launch: the kernel needs no per-chunk workspace, so a launch is as long as 32-bit chunk indices allow
     // comfortably (every launch ends in a tail of up to one chunk time per workgroup)
-    h->tile = h->two_launch ? 32768 : (1 << 20);
-    {
-        const size_t slots = h->two_launch ? (size_t)h->tile : (size_t)h->n_wg * S2S_MAX_GROUP;
-        if ((e = hipMalloc(&h->handoff, slots * S2S_SLOT_FLOATS * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(handoff)");
-    }
+    h->tile = 1 << 20;
+    if ((e = hipMalloc(&h->handoff, (size_t)h->n_wg * S2S_MAX_GROUP * S2S_SLOT_FLOATS * sizeof(float))) != hipSuccess)
+        return bail(e, "hipMalloc(handoff)");
     {   // export scratch for the streaming path's usual super-batch, so that its first s2s_export_reads does not have to
         // drain the stream in order to grow it
         const int cap = 2 * 32768 + 1;
@@ -1041,11 +994,9 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
         h->ws_export_cap = cap;
     }
     const struct { const void* fn; int bytes; } dyn_lds[] = {
-        {reinterpret_cast<const void*>(s2s_decoder_kernel<0>), DEC_LDS_F32}, {reinterpret_cast<const void*>(s2s_decoder_kernel<1>), DEC_LDS_H},
-        {reinterpret_cast<const void*>(s2s_decoder_kernel<3>), DEC_LDS_H},   {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), DEC_LDS_F32},
-        {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), DEC_LDS_H}, {reinterpret_cast<const void*>(s2s_fused_kernel<3, false>), DEC_LDS_H},
-        {reinterpret_cast<const void*>(s2s_fused_kernel<0, true>), DEC_LDS_F32}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, true>), DEC_LDS_H},
-        {reinterpret_cast<const void*>(s2s_fused_kernel<3, true>), DEC_LDS_H}};
+        {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), Fused<0>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), Fused<1>::LDS},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<3, false>), Fused<3>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<0, true>), Fused<0>::LDS},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<1, true>), Fused<1>::LDS},  {reinterpret_cast<const void*>(s2s_fused_kernel<3, true>), Fused<3>::LDS}};
     for (const auto& k : dyn_lds)
         if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(dynamic LDS)");
@@ -1106,36 +1057,16 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
         const dim3 grid(n < h->n_wg ? n : h->n_wg), block(DEC_WAVES * 64);
         const int mode = h->cfg.compute_mode;
         EventPair ev{};
-        if (h->two_launch) {
-            if (mode != S2S_MODE_F32)
-                hipLaunchKernelGGL(s2s_frontend_kernel<1>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, tb, tcs, n_valid + s, fc, P,
-                                   tg, tzdw, h->handoff, out_dur + s * 16, D, (long long)s);
-            else
-                hipLaunchKernelGGL(s2s_frontend_kernel<0>, dim3(n), dim3(64), 0, stream, h->model, h->d_arena, tb, tcs, n_valid + s, fc, P,
-                                   tg, tzdw, h->handoff, out_dur + s * 16, D, (long long)s);
-        }
         if (h->profiling) {
             HIP_TRY(h, hipEventCreate(&ev.a));
             HIP_TRY(h, hipEventCreate(&ev.b));
             HIP_TRY(h, hipEventRecord(ev.a, stream));
         }
-        if (h->two_launch) {
-            if (mode == S2S_MODE_F16)
-                hipLaunchKernelGGL(s2s_decoder_kernel<3>, grid, block, DEC_LDS_H, stream, h->model, h->d_arena, h->handoff, n, fc, P,
-                                   tz01, tsig, D, (long long)s);
-            else if (mode == S2S_MODE_F16X3)
-                hipLaunchKernelGGL(s2s_decoder_kernel<1>, grid, block, DEC_LDS_H, stream, h->model, h->d_arena, h->handoff, n, fc, P,
-                                   tz01, tsig, D, (long long)s);
-            else
-                hipLaunchKernelGGL(s2s_decoder_kernel<0>, grid, block, DEC_LDS_F32, stream, h->model, h->d_arena, h->handoff, n, fc, P,
-                                   tz01, tsig, D, (long long)s);
-        } else {
-            const bool test = dbg || inject_g || inject_zdw || inject_z01;
-            auto fused = test ? (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, true> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, true> : s2s_fused_kernel<0, true>)
-                              : (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, false> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, false> : s2s_fused_kernel<0, false>);
-            hipLaunchKernelGGL(fused, grid, block, mode == S2S_MODE_F32 ? DEC_LDS_F32 : DEC_LDS_H, stream, h->model, h->d_arena, tb, tcs,
-                               n_valid + s, n, fc, P, tg, tzdw, tz01, h->handoff, out_dur + s * 16, tsig, D, (long long)s);
-        }
+        const bool test = dbg || inject_g || inject_zdw || inject_z01;
+        auto fused = test ? (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, true> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, true> : s2s_fused_kernel<0, true>)
+                          : (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, false> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, false> : s2s_fused_kernel<0, false>);
+        hipLaunchKernelGGL(fused, grid, block, mode == S2S_MODE_F16 ? Fused<3>::LDS : mode == S2S_MODE_F16X3 ? Fused<1>::LDS : Fused<0>::LDS, stream, h->model, h->d_arena, tb, tcs,
+                           n_valid + s, n, fc, P, tg, tzdw, tz01, h->handoff, out_dur + s * 16, tsig, D, (long long)s);
         if (h->profiling) {
             HIP_TRY(h, hipEventRecord(ev.b, stream));
             ev.chunks = n;

@@ -5,11 +5,12 @@ f16 block: 1 no exp, 2 no split, 4 no barriers, 32 no max/branch, 64 no row-sum 
 S2S_ABL_FLAGS adds extra -D flags (e.g. -DS2S_NO_FALLBACK so that garbage data cannot take the safe softmax path)."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from seq2squiggle_amd import _build
 masks = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 31]
 for m in masks:
     lib = os.path.join(ROOT, "seq2squiggle_amd", "lib", f"libs2s_hip_abl{m}.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", f"-DS2S_ABL={m}", *os.environ.get("S2S_ABL_FLAGS", "").split(),
-                    "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
+    _build.compile_to(lib, [f"-DS2S_ABL={m}", *os.environ.get("S2S_ABL_FLAGS", "").split()])
     env = dict(os.environ, S2S_HIP_LIB=lib)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "420",
                         "--no-cpu-baseline", "--mode", os.environ.get("S2S_ABL_MODE", "f16x3")], env=env, capture_output=True, text=True)

@@ -4,8 +4,8 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "seq2squiggle_amd", "lib", "libs2s_hip_diag.so")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-DS2S_DIAG",
-                "-o", lib, os.path.join(ROOT, "seq2squiggle_amd", "csrc", "s2s_hip.hip")], check=True)
+from seq2squiggle_amd import _build
+_build.compile_to(lib, ["-DS2S_DIAG"])
 os.environ["S2S_HIP_LIB"] = lib
 import numpy as np, torch
 import seq2squiggle_amd as S
