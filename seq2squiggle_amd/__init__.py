@@ -10,3 +10,4 @@ __version__ = "0.1.0"
 from .checkpoint import load_checkpoint, state_dict_to_blob, config_to_c  # noqa: F401
 from .chunker import encode_read, encode_reads  # noqa: F401
 from .engine import Engine, PredictParams  # noqa: F401
+from .modules import Stages  # noqa: F401

@@ -9,6 +9,8 @@ set_seeds (722-741), setup_logging (687-719).  Training-only helpers (plots, par
 are out of scope.
 """
 import gzip
+import bisect
+import itertools
 import logging
 import os
 import math
@@ -43,25 +45,25 @@ def get_profile(profile: str) -> Dict[str, float]:
     return None
 
 
-def update_profile(profile_dict: dict, **kwargs) -> dict:
-    """Non-None overrides replace profile entries (utils.py:218-243)."""
-    for key, value in kwargs.items():
-        if value is not None and key in profile_dict:
-            profile_dict[key] = value
-        elif key not in profile_dict:
-            logger.warning(f"Warning: {key} is not a valid key in the profile")
+def update_profile(profile_dict: dict, **overrides) -> dict:
+    """CLI overrides of profile entries (reference utils.py:218-243): a None leaves the entry alone, an unknown key is
+    reported and ignored."""
+    for key in overrides.keys() - profile_dict.keys():
+        logger.warning(f"Warning: {key} is not a valid key in the profile")
+    profile_dict.update({k: v for k, v in overrides.items() if v is not None and k in profile_dict})
     return profile_dict
 
 
+_KMER_OF_CHEMISTRY = (("dna-r10", 9), ("rna-004", 9), ("dna-r9", 6))
+
+
 def update_config(profile_name: str, config: dict) -> dict:
-    """seq_kmer follows the chemistry (utils.py:245-263)."""
-    if profile_name.startswith("dna-r10") or profile_name.startswith("rna-004"):
-        config["seq_kmer"] = 9
-    elif profile_name.startswith("dna-r9"):
-        config["seq_kmer"] = 6
-    else:
-        raise ValueError(f"Unsupported profile name: {profile_name}. Expected 'dna-r10' or 'dna-r9' prefix.")
-    return config
+    """The k-mer size is a property of the chemistry, not of the YAML (reference utils.py:245-263)."""
+    for prefix, k in _KMER_OF_CHEMISTRY:
+        if profile_name.startswith(prefix):
+            config["seq_kmer"] = k
+            return config
+    raise ValueError(f"Unsupported profile name: {profile_name}. Expected 'dna-r10' or 'dna-r9' prefix.")
 
 
 # --------------------------------------------------------------------------------------- FASTA / FASTQ
@@ -106,22 +108,21 @@ def read_fasta(path: str, rna: bool = False) -> Generator[Tuple[str, str], None,
 
 
 # --------------------------------------------------------------------------------------- read sampling
-def draw_gamma_dis(mean, seed, total_len):
-    sample = st.gamma.rvs(6.3693711, 0.53834893, size=1, random_state=seed)
-    sample = int(sample[0] * mean / 4.39)
-    return np.clip(sample, 1, total_len)
+# Read-length laws (reference utils.py:311-331): a scipy distribution fitted to real runs, rescaled so that its mean is the
+# requested -r.  name -> (distribution, shape/loc/scale arguments, mean of the fitted law)
+_LENGTH_LAWS = {
+    "expon": (st.expon, dict(loc=213.98910256668592, scale=6972.5319847131141), 7106.0),
+    "beta": (st.beta, dict(a=1.778, b=7.892, loc=316.758, scale=34191.257), 6615.0),
+    "gamma": (st.gamma, dict(a=6.3693711, loc=0.53834893), 4.39),
+}
 
 
-def draw_beta_dis(mean, seed, total_len):
-    sample = st.beta.rvs(1.778, 7.892, 316.758, 34191.257, size=1, random_state=seed)
-    sample = (sample[0] * mean / 6615.0).astype(int)
-    return np.clip(sample, 1, total_len)
-
-
-def draw_expon_dis(mean, seed, total_len):
-    sample = st.expon.rvs(loc=213.98910256668592, scale=6972.5319847131141, size=1, random_state=seed)
-    sample = (sample[0] * mean / 7106.0).astype(int)
-    return np.clip(sample, 1, total_len)
+def draw_length(distr: str, mean, seed, total_len):
+    """One read length: a single variate from a generator seeded with `seed` (scipy builds a fresh legacy RandomState per
+    call), truncated to an integer and clipped to [1, total_len]."""
+    law, args, fitted_mean = _LENGTH_LAWS[distr]
+    x = law.rvs(size=1, random_state=seed, **args)[0]
+    return np.clip(int(x * mean / fitted_mean), 1, total_len)
 
 
 def _mt19937_first_double(seeds: np.ndarray) -> np.ndarray:
@@ -157,26 +158,23 @@ def _mt19937_first_double(seeds: np.ndarray) -> np.ndarray:
 
 
 def draw_expon_dis_many(mean, seeds: np.ndarray, total_len) -> np.ndarray:
-    """draw_expon_dis for a vector of seeds, bit-identical to the per-seed scipy call (tests/test_sampler_cpu.py): scipy
+    """draw_length("expon", ...) for a vector of seeds, bit-identical to the per-seed scipy call (tests/test_sampler_cpu.py): scipy
     seeds a fresh legacy RandomState per call and takes loc + scale * standard_exponential(), i.e. -log(1 - double)
     with the C library's log (math.log; np.log may differ in the last bit)."""
     e = np.array([-math.log(1.0 - x) for x in _mt19937_first_double(seeds)])
-    sample = ((213.98910256668592 + 6972.5319847131141 * e) * mean / 7106.0).astype(int)
+    _, args, fitted_mean = _LENGTH_LAWS["expon"]
+    sample = ((args["loc"] + args["scale"] * e) * mean / fitted_mean).astype(int)
     return np.clip(sample, 1, total_len)
 
 
-_DISTR = {"beta": draw_beta_dis, "gamma": draw_gamma_dis, "expon": draw_expon_dis}
 _COMPLEMENT = str.maketrans("ATCG", "TAGC")
 
 
-def get_genome_and_position(genome_lengths, random_position):
-    if random_position >= sum(genome_lengths):
-        raise ValueError("Random position exceeds the total length of genomes")
-    cumulative = 0
-    for i, length in enumerate(genome_lengths):
-        cumulative += length
-        if random_position < cumulative:
-            return i, random_position - (cumulative - length)
+def locate(contig_ends, position):
+    """Genome-wide coordinate -> (contig index, offset inside it); contig_ends = running sum of the contig lengths
+    (reference utils.py:359-372 walks the contigs instead)."""
+    i = bisect.bisect_right(contig_ends, position)
+    return i, position - (contig_ends[i - 1] if i else 0)
 
 
 def read_check(read, read_length, read_i, profile, min_read_len=30):
@@ -191,8 +189,11 @@ def read_check(read, read_length, read_i, profile, min_read_len=30):
     return True
 
 
-def N_to_ACTG(read):
-    return "".join(random.choice("ACGT") if base == "N" else base for base in read)
+def fill_unknown_bases(read: str) -> str:
+    """Every N becomes a uniformly drawn base: one draw from the global `random` stream per N, left to right (the order the
+    reference consumes them in, utils.py:402-403)."""
+    head, *rest = read.split("N")
+    return head + "".join(random.choice("ACGT") + piece for piece in rest)
 
 
 def reverse_complement(f):
@@ -225,35 +226,39 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
             blocks[level] = (lo, vals)
         return int(vals[read_i - lo])
 
+    contig_ends = list(itertools.accumulate(genome_lens))
+    is_dna = profile.startswith("dna")
+
+    def attempt(read_i, retry):
+        """One try at read `read_i`: the read (N's already replaced), its strand, or None when it is rejected.  Draw order
+        on the global `random` stream: start position, strand (DNA only), then the N replacements of an accepted read."""
+        where, offset = locate(contig_ends, random.randint(0, total_genome_len - 1))
+        genome = genome_seqs[where]
+        if r <= 0:
+            length = len(genome)
+        elif fast:
+            length = fast_length(read_i, retry)
+        else:
+            length = int(draw_length(distr, r, seed + read_i * (max_retries + 1) + retry, total_len))
+        read = genome[offset:offset + length]
+        strand = random.choice("+-") if is_dna else "+"
+        if not read_check(read, length, read_i, profile, min_read_len):
+            return None
+        return (fill_unknown_bases(read) if "N" in read else read), strand
+
     for read_i in range(num_seqs):
-        retries = 0
-        while retries < max_retries:
-            start_pos = random.randint(0, total_genome_len - 1)
-            genome_index, start_index = get_genome_and_position(genome_lens, start_pos)
-            genome = genome_seqs[genome_index]
-            unique_seed = seed + read_i * (max_retries + 1) + retries
-            if fast:
-                read_length = fast_length(read_i, retries)
+        for retry in range(max_retries):
+            got = attempt(read_i, retry)
+            if got is None:
+                continue
+            read, strand = got
+            if materialise is not None and not (materialise[0] <= len(sampled_reads) < materialise[1]):
+                sampled_reads.append(len(read))
             else:
-                read_length = int(_DISTR[distr](r, unique_seed, total_len)) if r > 0 else len(genome)
-            read = genome[start_index:start_index + read_length]
-            if profile.startswith("dna"):
-                read_strand = random.choice("+-")
-            elif profile.startswith("rna"):
-                read_strand = "+"
-            if read_check(read, read_length, read_i, profile, min_read_len):
-                if "N" in read:
-                    read = N_to_ACTG(read)                 # (draws from `random`: never skipped)
-                if materialise is not None and not (materialise[0] <= len(sampled_reads) < materialise[1]):
-                    sampled_reads.append(len(read))
-                    break
-                if read_strand == "-":
-                    read = reverse_complement(read)
-                sampled_reads.append(read)
-                break
-            retries += 1
-            if retries >= max_retries:
-                logger.debug(f"Failed to sample a valid read after {max_retries} retries for read {read_i}. Skipping this read.")
+                sampled_reads.append(reverse_complement(read) if strand == "-" else read)
+            break
+        else:
+            logger.debug(f"Failed to sample a valid read after {max_retries} retries for read {read_i}. Skipping this read.")
     return sampled_reads
 
 

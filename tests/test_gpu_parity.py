@@ -74,6 +74,39 @@ CASES = [
 ]
 
 
+def test_submodule_call_surface(case):
+    """The reference's Encoder / NoiseSampler / LengthRegulator / Decoder signatures (modules.py:65-89, 275-278, 396-441,
+    133-142), chained as predict_step chains them (model.py:197-221), against the stage goldens -- including the two the
+    kernel never materialises: the length-regulated tensor (through its row sums) and the expanded sigma."""
+    from seq2squiggle_amd.modules import Stages
+    g, eng = case["g"], case["eng"]
+    codes = torch.from_numpy(g["codes"].astype(np.int64))
+    onehot = torch.zeros(*codes.shape, 5)
+    known = codes < 5
+    onehot[known] = torch.nn.functional.one_hot(codes[known], 5).float()        # unknown letters: all-zero rows (utils.py:86)
+    st = Stages(eng, S.PredictParams(**P(noise_std=0.0)), inject_g=dev_t(case, "g"))
+    x = onehot.reshape(codes.shape[0], 16, -1).to(case["dev"])                  # model.py:197-198
+    enc_out, emb_out = st.encoder(x)
+    sigma = st.noise_sampler(emb_out)
+    out, dur, dist, noise_ext, _ = st.length_regulator(emb_out, enc_out, sigma, dwell_mean=12.5, dwell_std=0.0,
+                                                       duration_sampling=True, min_length=3)
+    y = st.decoder(out)
+    tol = 2e-5 if eng.mode == "f32" else 6e-5
+    assert enc_out.shape == emb_out.shape == (codes.shape[0], 16, 64) and sigma.shape == (codes.shape[0], 16, 1)
+    assert np.abs(enc_out.cpu().numpy() - g["enc_out"]).max() < tol and np.abs(emb_out.cpu().numpy() - g["emb_out"]).max() < tol
+    assert np.abs(sigma[..., 0].cpu().numpy() - g["sigma"]).max() < tol
+    assert np.array_equal(dur.cpu().numpy(), g["dur_gamma"].astype(np.float32))
+    assert out.shape == (codes.shape[0], 250, 64) and noise_ext.shape == (codes.shape[0], 250, 1) and y.shape == (codes.shape[0], 250, 1)
+    assert np.abs(out.sum(-1).cpu().numpy() - g["lr_rowsum_gamma"]).max() < 64 * tol
+    assert np.abs(noise_ext[..., 0].cpu().numpy() - g["sigma_ext_gamma"]).max() < tol
+    assert np.abs(y[..., 0].cpu().numpy() - g["y_scaled_gamma"]).max() < tol
+    assert torch.allclose(dist.concentration.cpu(), torch.from_numpy(g["conc"]), rtol=3e-5, atol=3e-5)
+    with pytest.raises(ValueError):
+        st.decoder(out + 1.0)                                                    # not the batch the previous stage produced
+    with pytest.raises(ValueError):
+        st.length_regulator(emb_out, enc_out, sigma, dwell_mean=9.0)
+
+
 @pytest.mark.parametrize("key,over,use_g,use_z,use_zdw", CASES)
 def test_predict_modes_vs_reference_goldens(case, key, over, use_g, use_z, use_zdw):
     g, eng = case["g"], case["eng"]

@@ -58,7 +58,7 @@ def test_vectorised_length_draws_equal_the_per_seed_scipy_call():
     seeds = np.concatenate([np.arange(0, 300), 42 + 21 * np.arange(2000), np.array([2 ** 31 - 1, 2 ** 32 - 1, 123456789])])
     for mean in (5000, 150, 20000):
         fast = U.draw_expon_dis_many(mean, seeds, 48502)
-        ref = np.array([int(U.draw_expon_dis(mean, int(sd), 48502)) for sd in seeds[::7]])
+        ref = np.array([int(U.draw_length("expon", mean, int(sd), 48502)) for sd in seeds[::7]])
         assert np.array_equal(fast[::7], ref)
 
 
