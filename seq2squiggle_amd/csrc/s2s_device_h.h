@@ -632,3 +632,182 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
     DIAG_STAMP(6);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One ENCODER FFTBlock (layers.py:116-142) for NQ independent 16-position sequences (one chunk each) owned by ONE wave, with the
+// attention entirely in registers: with T = 16 a head pair's K^T, V^T and Q^T are single accumulator tiles, and
+//   * a K^T tile (lane (g, c): features 4g..4g+3 of key c) IS the A operand of the score MFMA -- its eight k-slots take the
+//     four features' hi halves and their lo halves -- against B = [Q_hi | Q_hi] and [Q_lo | 0] of the same lanes (A and B
+//     fragments of the K = 32 MFMA share one lane layout); the contraction then runs over the pair's 16 features, so the
+//     other head's lane groups are zeroed in B (head 2p: groups 0-1, head 2p+1: groups 2-3);
+//   * the operand-swapped V GEMM leaves V^T (lane (g, c): keys 4g..4g+3 of feature c), the A operand of the P.V MFMA,
+//     against B = [P_hi | P_hi] and [P_lo | 0] straight from the score tile's layout (rows = keys, column = query); the
+//     product's rows are the pair's 16 features, of which head 2p owns 0-7 (lane groups 0-1) and head 2p+1 the rest.
+// No LDS, no barrier, no re-layout; the eight softmaxes of a sequence are independent 16x16 tiles (the decoder's version of
+// this code streams 256 keys through LDS instead).  Products are the same three f16 terms as everywhere else.
+// ws: the layer's f16 weight stream (pack_layer: units 0-7 Wk/Wv per pair, 8-15 Wq/Wfc per two pairs, 16-47 the FFN).
+template <int NQ>
+__device__ __forceinline__ void enc_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4], const int lane,
+                                            const float one, unsigned long long* diag_buf = nullptr) {
+    const int g = lane >> 4, c = lane & 15;
+    DIAG_DECL;
+    const float* ws = W + L.stream_h + lane * 4;
+    constexpr int UF = 1024;                                          // floats per unit
+    f32x4 fk[4], fv[4], fq[4], fc0[4], fc1[4];
+    load_unit_h<true>(fk, ws);                                        // Wk, Wv of pair 0, Wq(0)
+    load_unit_h<true>(fv, ws + UF);
+    load_unit_h<true>(fq, ws + 8 * UF);
+
+    HL xb[NQ][2];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
+    f32x4 acc[NQ][4];                                                 // fc accumulator: bias + residual (layers.py:85-86)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = ldg4(W + L.bfc + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
+    }
+    const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8): scores in log2 units
+    const bool low = g < 2;                                           // lane groups of the pair's first head
+    DIAG_STAMP(0);
+#pragma unroll 1
+    for (int u = 0; u < 2; ++u) {
+        load_unit_h<true>(fc0, ws + (8 + 4 * u + 2) * UF);            // Wfc(u): m-tiles 0-1, 2-3
+        load_unit_h<true>(fc1, ws + (8 + 4 * u + 3) * UF);
+        f32x4 opair[2][NQ];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int p = 2 * u + pp;
+            const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g), bq = ldg4(W + L.bq_nat + 16 * p + 4 * g);
+            const float bv = W[L.bv + 16 * p + c];                    // V comes out transposed: this lane's column is one feature
+            SB_GEMM();
+            f32x4 ak[NQ], av[NQ], aq[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; aq[q] = f32x4{0, 0, 0, 0}; }
+            mm_unit_h<NQ>(ak, fk, xb);
+            mm_unit_h_t<NQ>(av, fv, xb);
+            mm_unit_h<NQ>(aq, fq, xb);
+            SB_GEMM();
+            {   // the next pair's units, requested behind this pair's softmaxes (after the last pair: harmless re-reads)
+                const int pn = p < 3 ? p + 1 : 3;
+                load_unit_h<true>(fk, ws + (2 * pn) * UF);
+                load_unit_h<true>(fv, ws + (2 * pn + 1) * UF);
+                load_unit_h<true>(fq, ws + (8 + 4 * (pn >> 1) + (pn & 1)) * UF);
+            }
+            SB_GEMM();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                h4 khi, klo, vhi, vlo, qhi, qlo;
+                split4(ak[q] + bk, one, khi, klo);
+                split4(av[q] + bv, one, vhi, vlo);
+                split4((aq[q] + bq) * c1, one, qhi, qlo);
+                const uv2 kh = __builtin_bit_cast(uv2, khi), kl = __builtin_bit_cast(uv2, klo);
+                const uv2 vh = __builtin_bit_cast(uv2, vhi), vl = __builtin_bit_cast(uv2, vlo);
+                const uv2 qh = __builtin_bit_cast(uv2, qhi), ql = __builtin_bit_cast(uv2, qlo);
+                const h8 Ka = __builtin_bit_cast(h8, (uv4{kh[0], kh[1], kl[0], kl[1]}));
+                const h8 Va = __builtin_bit_cast(h8, (uv4{vh[0], vh[1], vl[0], vl[1]}));
+                f32x4 O[2];
+                float inv[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const bool mine = (hh == 0) == low;               // this lane group carries features of head 2p + hh
+                    const h8 Q1 = __builtin_bit_cast(h8, (uv4{mine ? qh[0] : 0u, mine ? qh[1] : 0u, mine ? qh[0] : 0u, mine ? qh[1] : 0u}));
+                    const h8 Q2 = __builtin_bit_cast(h8, (uv4{mine ? ql[0] : 0u, mine ? ql[1] : 0u, 0u, 0u}));
+                    f32x4 s = MFMAH(Ka, Q1, (f32x4{0, 0, 0, 0}));     // rows: keys 4g..4g+3, column: query c
+                    s = MFMAH(Ka, Q2, s);
+                    const float m = max_g(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+                    const float e0 = __builtin_amdgcn_exp2f(s[0] - m), e1 = __builtin_amdgcn_exp2f(s[1] - m);
+                    const float e2 = __builtin_amdgcn_exp2f(s[2] - m), e3 = __builtin_amdgcn_exp2f(s[3] - m);
+                    unsigned h0, h1, l0, l1;
+                    split2(e0, e1, one, h0, l0);
+                    split2(e2, e3, one, h1, l1);
+                    const h8 P1 = __builtin_bit_cast(h8, (uv4{h0, h1, h0, h1}));
+                    const h8 P2 = __builtin_bit_cast(h8, (uv4{l0, l1, 0u, 0u}));
+                    inv[hh] = 1.0f / sum_g((e0 + e1) + (e2 + e3));   // (the halves above carry these to 22 bits)
+                    O[hh] = MFMAH(Va, P1, (f32x4{0, 0, 0, 0}));       // rows: the pair's features 4g..4g+3, column: query c
+                    O[hh] = MFMAH(Va, P2, O[hh]);
+                }
+                opair[pp][q] = low ? O[0] * inv[0] : O[1] * inv[1];
+            }
+        }
+        // ---- fc, k-block u (the 4 heads just finished): acc += Wfc[:, 32u : 32u+32] * O^T
+        HL ob[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ob[q] = split8(opair[0][q], opair[1][q], one);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const h8 wh = as_h8(half == 0 ? fc0[2 * mm] : fc1[2 * mm]);
+                const h8 wl = as_h8(half == 0 ? fc0[2 * mm + 1] : fc1[2 * mm + 1]);
+                const int mt = 2 * half + mm;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].hi, acc[q][mt]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].lo, acc[q][mt]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wl, ob[q].hi, acc[q][mt]);
+            }
+    }
+    DIAG_STAMP(3);
+
+    // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113), weights streamed three units
+    //      ahead through a ring of four unit buffers (8 units per slice: slots repeat)
+    const float* wf = ws + 16 * UF;
+    f32x4 ring[4][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) load_unit_h<true>(ring[i], wf + i * UF);
+    wf += 3 * UF;
+    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+    DIAG_STAMP(4);
+    HL x1b[NQ][2];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1], one); x1b[q][1] = split8(acc[q][2], acc[q][3], one); }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;      // X = bias + residual accumulator
+    }
+#pragma unroll 1
+    for (int hc = 0; hc < 4; ++hc) {
+        f32x4 hid[NQ][4], b1[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {              // W1 units: rows 64hc + 16mt ..
+            f32x4 t[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
+            load_unit_h<true>(ring[(mt + 3) & 3], wf);               // (runs three units past the stream's end: pack_layer pads it)
+            wf += UF;
+            SB_GEMM();
+            mm_unit_h<NQ>(t, ring[mt & 3], x1b);
+            SB_GEMM();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r] + b1[mt][r], 0.0f);
+        }
+        HL hb[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1], one); hb[q][1] = split8(hid[q][2], hid[q][3], one); }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
+            f32x4 t[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
+            load_unit_h<true>(ring[(mt + 3) & 3], wf);
+            wf += UF;
+            SB_GEMM();
+            mm_unit_h<NQ>(t, ring[mt & 3], hb);
+            SB_GEMM();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
+        }
+    }
+    DIAG_STAMP(5);
+    layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+    DIAG_STAMP(6);
+}

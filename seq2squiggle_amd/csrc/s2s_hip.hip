@@ -243,7 +243,7 @@ __device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* 
     DIAG_STAMP(5);
 #pragma unroll 1
     for (int l = 0; l < M.enc_layers; ++l) {
-        if constexpr (MODE == 1) fft_block_h<NQ, 1, 1, 16, true, (NQ > 1)>(W, M.enc[l], X, lds_raw, 0, 0, lane, one, diag_blk);
+        if constexpr (MODE == 1) enc_block_h<NQ>(W, M.enc[l], X, lane, one, diag_blk);
         else                     fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane, diag_blk);
     }
     DIAG_STAMP(2);
