@@ -56,6 +56,9 @@ struct DebugDev {
         diag_t_ = n_;                                                               \
         __builtin_amdgcn_sched_barrier(0);                                          \
     } while (0)
+#elif defined(S2S_STAMP_SB)
+#define DIAG_DECL
+#define DIAG_STAMP(slot) __builtin_amdgcn_sched_barrier(0)
 #else
 #define DIAG_DECL
 #define DIAG_STAMP(slot)

@@ -112,23 +112,19 @@ __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h
 
 // LDS of the f16 block: K [head][hi|lo][key][8 d] halves, V^T [head][16 rows: 0-7 hi d, 8-15 lo d][VS keys]
 // halves, and a per-wave scratch for the Q^T operand re-layout.
-// SEP (the encoder in the fused kernel): the wave's NQ time tiles are NQ independent 16-position sequences (one chunk each),
-// every one with its own K/V image of 16 keys; NKT = 1, WAVES = 1 describe one of them.
-template <int NQ, int WAVES, int NKT = 16, bool SEP = false> struct AttnLdsH {
+template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
     static constexpr int KEYS = 16 * NKT;
     static constexpr int K_BYTES = 8 * 2 * KEYS * 8 * 2;
     // halves per V^T row.  NKT even (the decoder): a row is stored as [32-key block][lane group g][8 halves] -- the 4 keys 4g..4g+3 of
     // the block's first tile, then those of its second -- so the P.V operand of a K = 32 block is ONE ds_read_b128 per lane;
     // 272 halves = 136 dwords == 8 (mod 64) makes the 16 lanes of every b128 lane group hit 16 distinct 4-dword bank slots.
     // (The natural key order needed two b64 reads, which hipcc fuses into ds_read2_b64: banked mod 32, 2-way conflicts on
-    // every access -- the 11,264 SQ_LDS_BANK_CONFLICT cycles per chunk of profiles/r01.)  NKT = 1 (encoder): natural order
-    // (SEP: unpadded rows, so that the 16 sequences of a workgroup fit beside each other).
+    // every access -- the 11,264 SQ_LDS_BANK_CONFLICT cycles per chunk of profiles/r01.)  Odd NKT: natural order.
     static constexpr bool V128 = (NKT % 2) == 0;
-    static constexpr int VS = V128 ? KEYS + 16 : (SEP ? KEYS : KEYS + 8);
+    static constexpr int VS = V128 ? KEYS + 16 : KEYS + 8;
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
-    static constexpr int SEQ_HALVES = (K_BYTES + V_BYTES) / 2;          // one sequence's K and V images
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
-    static constexpr int BYTES = (SEP ? NQ : 1) * (K_BYTES + V_BYTES) + WAVES * Q_WAVE_BYTES;
+    static constexpr int BYTES = K_BYTES + V_BYTES + WAVES * Q_WAVE_BYTES;
 };
 
 // acc[q] += W_unit * x[q]: one 16-row m-tile, K = 64 as two k-blocks, three products each.
@@ -193,13 +189,11 @@ __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const f
 //     shift-invariant, so this is exact as long as no later score beats m by the f16 range of P_hi; if one does, the
 //     row sum turns inf/NaN, which the caller checks once per head, and then runs
 //   SAFE = true (rare): a textbook online softmax, the running max raised and the sums rescaled in every pass.
-template <int NQ, int NKT, int TV, bool SAFE, bool LO = true, bool SEP = false>
+template <int NQ, int NKT, int TV, bool SAFE, bool LO = true>
 __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, const _Float16* __restrict__ vp, const h8 (&qb)[NQ],
                                            const h8 ones, const float one, const int g, f32x4 (&oH)[NQ], f32x4 (&oL)[NQ],
                                            f32x4 (&lH)[NQ], f32x4 (&lL)[NQ]) {
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;
-    constexpr int NS = SEP ? NQ : 1;                   // K/V images: one for all tiles, or one per tile (SEP)
-    constexpr int SEQ = AttnLdsH<NQ, 1, NKT, SEP>::SEQ_HALVES;
     f32x4 negm[NQ];
     float m[NQ];
 #pragma unroll
@@ -211,21 +205,18 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
     }
 #pragma unroll
     for (int h2 = 0; h2 < ((S2S_ABL & 256) ? 1 : NH); ++h2) {
-        h8 ka[NS][HK], va[NS][HB];
+        h8 ka[HK], va[HB];
 #pragma unroll
-        for (int sq = 0; sq < NS; ++sq) {
+        for (int kt = 0; kt < HK; ++kt) ka[kt] = *reinterpret_cast<const h8*>(kp + 16 * (h2 * HK + kt) * 8);
 #pragma unroll
-            for (int kt = 0; kt < HK; ++kt) ka[sq][kt] = *reinterpret_cast<const h8*>(kp + sq * SEQ + 16 * (h2 * HK + kt) * 8);
-#pragma unroll
-            for (int kb = 0; kb < HB; ++kb) {
-                if (AttnLdsH<NQ, 1, NKT, SEP>::V128) {    // (vp already points at this lane group's 8 halves of block 0)
-                    va[sq][kb] = *reinterpret_cast<const h8*>(vp + sq * SEQ + 32 * (h2 * HB + kb));
-                } else {
-                    const h4 v0 = *reinterpret_cast<const h4*>(vp + sq * SEQ + 16 * (h2 * HK + 2 * kb));
-                    h4 v1 = h4{0, 0, 0, 0};                // a K = 32 block past the last key tile: zero keys
-                    if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + sq * SEQ + 16 * (h2 * HK + 2 * kb + 1));
-                    va[sq][kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                }
+        for (int kb = 0; kb < HB; ++kb) {
+            if (AttnLdsH<NQ, 1, NKT>::V128) {              // (vp already points at this lane group's 8 halves of block 0)
+                va[kb] = *reinterpret_cast<const h8*>(vp + 32 * (h2 * HB + kb));
+            } else {
+                const h4 v0 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb));
+                h4 v1 = h4{0, 0, 0, 0};                    // a K = 32 block past the last key tile: zero keys
+                if (2 * kb + 1 < HK) v1 = *reinterpret_cast<const h4*>(vp + 16 * (h2 * HK + 2 * kb + 1));
+                va[kb] = h8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             }
         }
         SB_ATT();
@@ -236,7 +227,7 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int kt = 0; kt < HK; ++kt)
-                s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[SEP ? q : 0][kt])) : (h2 == 0) ? MFMAH(ka[SEP ? q : 0][kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[SEP ? q : 0][kt], qb[q], negm[q]);
+                s[q][kt] = (S2S_ABL & 1024) ? (negm[q] + __builtin_bit_cast(f32x4, ka[kt])) : (h2 == 0) ? MFMAH(ka[kt], qb[q], (f32x4{0, 0, 0, 0})) : MFMAH(ka[kt], qb[q], negm[q]);
         if (TV < 16 * NKT && h2 == NH - 1) {       // phantom keys -> -inf (only the last key tile has any)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -262,7 +253,7 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
                     // "score - m" comes from the matrix cores again: 8 issue cycles per tile instead of four subtractions (16)
                     if (!SAFE && !(TV < 16 * NKT && NH == 1)) {
 #pragma unroll
-                        for (int kt = 0; kt < HK; ++kt) s[q][kt] = MFMAH(ka[SEP ? q : 0][kt], qb[q], negm[q]);
+                        for (int kt = 0; kt < HK; ++kt) s[q][kt] = MFMAH(ka[kt], qb[q], negm[q]);
                     } else {                                      // (a single-pass block has already masked its phantom keys in s)
 #pragma unroll
                         for (int kt = 0; kt < HK; ++kt) s[q][kt] -= mh;
@@ -293,8 +284,8 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
 #pragma unroll
             for (int kb = 0; kb < HB; ++kb) {
                 if (S2S_ABL & 512) { asm volatile("" ::"v"(P[q][kb].hi), "v"(P[q][kb].lo)); continue; }
-                oH[q] = MFMAH(va[SEP ? q : 0][kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
-                if (LO) oL[q] = MFMAH(va[SEP ? q : 0][kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
+                oH[q] = MFMAH(va[kb], P[q][kb].hi, oH[q]);  // rows 0-7: V_hi.P_hi, rows 8-15: V_lo.P_hi
+                if (LO) oL[q] = MFMAH(va[kb], P[q][kb].lo, oL[q]);  // rows 0-7: V_hi.P_lo, rows 8-15: V_lo.P_lo
                 if (!(S2S_ABL & 64)) {
                 lH[q] = MFMAH(ones, P[q][kb].hi, lH[q]);    // every row: sum of the P actually used
                 if (LO) lL[q] = MFMAH(ones, P[q][kb].lo, lL[q]);
@@ -318,19 +309,18 @@ __device__ __forceinline__ void load_unit_h(f32x4 (&f)[4], const float* __restri
 }
 
 // One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
-template <int NQ, int WAVES, int NKT, int TV, bool LO = true, bool SEP = false>
+template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr, const float* __restrict__ pf_src = nullptr,
                                             float* __restrict__ pf_dst = nullptr) {
-    using G = AttnLdsH<NQ, WAVES, NKT, SEP>;
-    static_assert(!SEP || (WAVES == 1 && NKT == 1), "SEP: every time tile is a one-tile sequence owned by this wave");
+    using G = AttnLdsH<NQ, WAVES, NKT>;
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
     _Float16* __restrict__ Vl = reinterpret_cast<_Float16*>(lds + G::K_BYTES);
-    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + (SEP ? NQ : 1) * (G::K_BYTES + G::V_BYTES) + wave * G::Q_WAVE_BYTES);
+    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + wave * G::Q_WAVE_BYTES);
     constexpr int UF = LO ? 1024 : 512;             // floats per weight unit: hi+lo fragments, or the hi-only stream
     const float* ws = W + (LO ? L.stream_h : L.stream_f) + lane * 4;
     f32x4 fa[4], fb[4];
@@ -365,17 +355,16 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         const int vrow = (2 * p + (c >> 3)) * 16 + (c & 7);    // V^T row of this lane's feature (hi; lo is 8 rows below)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int T = SEP ? 0 : qt0 + q;                          // the tile's place in its sequence
-            const int sq = SEP ? q * G::SEQ_HALVES : 0;               // ... and the sequence's K/V images
+            const int T = qt0 + q;
             const int key = 16 * T + c;
             h4 hi, lo;
             split4<LO>(ak[q] + bk, one, hi, lo);
-            *reinterpret_cast<h4*>(Kl + sq + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
-            *reinterpret_cast<h4*>(Kl + sq + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
+            *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
+            *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
             split4<LO>(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
             const int vcol = G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
-            *reinterpret_cast<h4*>(Vl + sq + vrow * G::VS + vcol) = hi;
-            *reinterpret_cast<h4*>(Vl + sq + (vrow + 8) * G::VS + vcol) = lo;
+            *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
+            *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
         }
     }
     // ---- fc accumulator starts as bias + residual (layers.py:85-86)
@@ -439,7 +428,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 const _Float16* kp = Kl + ((head * 2 + (g >> 1)) * G::KEYS + c) * 8;   // [K_hi | K_hi | K_lo | K_lo]
                 const _Float16* vp = Vl + (head * 16 + c) * G::VS + (G::V128 ? 8 : 4) * g;   // row c: 0-7 V_hi d, 8-15 V_lo d
                 f32x4 oH[NQ], oL[NQ], lH[NQ], lL[NQ];
-                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0, LO, SEP>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                softmax_pv<NQ, NKT, TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
 #if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)   // (NO_FALLBACK: test-only build, proves test_peaked_attention... needs the redo)
                 {
                     bool bad = false;                          // inf or NaN row sum: some P_hi left the f16 range
@@ -449,7 +438,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #ifdef S2S_DIAG
                     if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
 #endif
-                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO, SEP>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
                 }
 #endif
 #pragma unroll
@@ -634,7 +623,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// One ENCODER FFTBlock (layers.py:116-142) for NQ independent 16-position sequences (one chunk each) owned by ONE wave, with the
+// The ENCODER FFTBlock (layers.py:116-142) for NQ independent 16-position sequences (one chunk each) owned by ONE wave, with the
 // attention entirely in registers: with T = 16 a head pair's K^T, V^T and Q^T are single accumulator tiles, and
 //   * a K^T tile (lane (g, c): features 4g..4g+3 of key c) IS the A operand of the score MFMA -- its eight k-slots take the
 //     four features' hi halves and their lo halves -- against B = [Q_hi | Q_hi] and [Q_lo | 0] of the same lanes (A and B
@@ -643,38 +632,38 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 //   * the operand-swapped V GEMM leaves V^T (lane (g, c): keys 4g..4g+3 of feature c), the A operand of the P.V MFMA,
 //     against B = [P_hi | P_hi] and [P_lo | 0] straight from the score tile's layout (rows = keys, column = query); the
 //     product's rows are the pair's 16 features, of which head 2p owns 0-7 (lane groups 0-1) and head 2p+1 the rest.
-// No LDS, no barrier, no re-layout; the eight softmaxes of a sequence are independent 16x16 tiles (the decoder's version of
-// this code streams 256 keys through LDS instead).  Products are the same three f16 terms as everywhere else.
-// ws: the layer's f16 weight stream (pack_layer: units 0-7 Wk/Wv per pair, 8-15 Wq/Wfc per two pairs, 16-47 the FFN).
-template <int NQ>
-__device__ __forceinline__ void enc_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4], const int lane,
-                                            const float one, unsigned long long* diag_buf = nullptr) {
-    const int g = lane >> 4, c = lane & 15;
-    DIAG_DECL;
-    const float* ws = W + L.stream_h + lane * 4;
-    constexpr int UF = 1024;                                          // floats per unit
-    f32x4 fk[4], fv[4], fq[4], fc0[4], fc1[4];
-    load_unit_h<true>(fk, ws);                                        // Wk, Wv of pair 0, Wq(0)
-    load_unit_h<true>(fv, ws + UF);
-    load_unit_h<true>(fq, ws + 8 * UF);
+// No LDS image of K/V, no barrier, no re-layout; the eight softmaxes of a sequence are independent 16x16 tiles (the decoder's
+// version of this code streams 256 keys through LDS instead).  Products are the same three f16 terms as everywhere else.
+//
+// `wl`: the layer's f16 weight units (1024 floats each; this lane's 16 bytes of every fragment at + 4 * lane) in the order of
+// pack_layer's stream, read straight from L2.
 
+// attention half: X (block input) -> acc = fc(attention) + bias + residual (layers.py:74-86).  wl: the layer's units 0-15.
+template <int NQ>
+__device__ __forceinline__ void enc_attention_h(const float* __restrict__ W, const LayerOff L, const float* __restrict__ wl,
+                                                const f32x4 (&X)[NQ][4], f32x4 (&acc)[NQ][4], const int lane, const float one) {
+    const int g = lane >> 4, c = lane & 15;
+    constexpr int UF = 1024;                                          // floats per unit
+    wl += lane * 4;
+    f32x4 fk[4], fv[4], fq[4], fc0[4], fc1[4];
+    load_unit_h<true>(fk, wl);                                        // Wk, Wv of pair 0, Wq(0)
+    load_unit_h<true>(fv, wl + UF);
+    load_unit_h<true>(fq, wl + 8 * UF);
     HL xb[NQ][2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
-    f32x4 acc[NQ][4];                                                 // fc accumulator: bias + residual (layers.py:85-86)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < 4; ++mt) {                                  // fc accumulator: bias + residual
         const f32x4 b = ldg4(W + L.bfc + 16 * mt + 4 * g);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8): scores in log2 units
     const bool low = g < 2;                                           // lane groups of the pair's first head
-    DIAG_STAMP(0);
 #pragma unroll 1
     for (int u = 0; u < 2; ++u) {
-        load_unit_h<true>(fc0, ws + (8 + 4 * u + 2) * UF);            // Wfc(u): m-tiles 0-1, 2-3
-        load_unit_h<true>(fc1, ws + (8 + 4 * u + 3) * UF);
+        load_unit_h<true>(fc0, wl + (8 + 4 * u + 2) * UF);            // Wfc(u): m-tiles 0-1, 2-3
+        load_unit_h<true>(fc1, wl + (8 + 4 * u + 3) * UF);
         f32x4 opair[2][NQ];
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
@@ -691,9 +680,9 @@ __device__ __forceinline__ void enc_block_h(const float* __restrict__ W, const L
             SB_GEMM();
             {   // the next pair's units, requested behind this pair's softmaxes (after the last pair: harmless re-reads)
                 const int pn = p < 3 ? p + 1 : 3;
-                load_unit_h<true>(fk, ws + (2 * pn) * UF);
-                load_unit_h<true>(fv, ws + (2 * pn + 1) * UF);
-                load_unit_h<true>(fq, ws + (8 + 4 * (pn >> 1) + (pn & 1)) * UF);
+                load_unit_h<true>(fk, wl + (2 * pn) * UF);
+                load_unit_h<true>(fv, wl + (2 * pn + 1) * UF);
+                load_unit_h<true>(fq, wl + (8 + 4 * (pn >> 1) + (pn & 1)) * UF);
             }
             SB_GEMM();
 #pragma unroll
@@ -740,50 +729,58 @@ __device__ __forceinline__ void enc_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 const h8 wh = as_h8(half == 0 ? fc0[2 * mm] : fc1[2 * mm]);
-                const h8 wl = as_h8(half == 0 ? fc0[2 * mm + 1] : fc1[2 * mm + 1]);
+                const h8 wlo = as_h8(half == 0 ? fc0[2 * mm + 1] : fc1[2 * mm + 1]);
                 const int mt = 2 * half + mm;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].hi, acc[q][mt]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wh, ob[q].lo, acc[q][mt]);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wl, ob[q].hi, acc[q][mt]);
+                for (int q = 0; q < NQ; ++q) acc[q][mt] = MFMAH(wlo, ob[q].hi, acc[q][mt]);
             }
     }
-    DIAG_STAMP(3);
+}
 
-    // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113), weights streamed three units
-    //      ahead through a ring of four unit buffers (8 units per slice: slots repeat)
-    const float* wf = ws + 16 * UF;
-    f32x4 ring[4][4];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) load_unit_h<true>(ring[i], wf + i * UF);
-    wf += 3 * UF;
+// FFN entry: acc = attention output -> x1 = LN1(acc), its B operands x1b, and X = x1 + b2 (the FFN's accumulator; layers.py:108-113)
+template <int NQ>
+__device__ __forceinline__ void enc_ffn_begin_h(const float* __restrict__ W, const LayerOff L, f32x4 (&acc)[NQ][4], f32x4 (&X)[NQ][4],
+                                                HL (&x1b)[NQ][2], const int lane, const float one) {
+    const int g = lane >> 4;
     layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
-    DIAG_STAMP(4);
-    HL x1b[NQ][2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1], one); x1b[q][1] = split8(acc[q][2], acc[q][3], one); }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;      // X = bias + residual accumulator
+        for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;
     }
-#pragma unroll 1
-    for (int hc = 0; hc < 4; ++hc) {
+}
+
+// two of the FFN's four 64-wide hidden slices: X += W2[:, slice] relu(W1[slice] x1 + b1[slice]) for hc = hc0, hc0 + 1.
+// wl: the 16 staged units of these slices (per slice: 4 of W1, then 4 of W2), read one unit ahead of use.
+template <int NQ>
+__device__ __forceinline__ void enc_ffn_half_h(const float* __restrict__ W, const LayerOff L, const float* __restrict__ wl, const int hc0,
+                                               const HL (&x1b)[NQ][2], f32x4 (&X)[NQ][4], const int lane, const float one) {
+    const int g = lane >> 4;
+    constexpr int UF = 1024;
+    wl += lane * 4;
+    f32x4 ring[2][4];
+    load_unit_h<true>(ring[0], wl);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
         f32x4 hid[NQ][4], b1[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
+        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(W + L.b1 + 64 * (hc0 + h) + 16 * mt + 4 * g);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W1 units: rows 64hc + 16mt ..
+            const int un = 8 * h + mt;                // this unit's index inside wl; the next one is requested now
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
-            load_unit_h<true>(ring[(mt + 3) & 3], wf);               // (runs three units past the stream's end: pack_layer pads it)
-            wf += UF;
+            load_unit_h<true>(ring[(un + 1) & 1], wl + (un + 1) * UF);
             SB_GEMM();
-            mm_unit_h<NQ>(t, ring[mt & 3], x1b);
+            mm_unit_h<NQ>(t, ring[un & 1], x1b);
             SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -795,19 +792,16 @@ __device__ __forceinline__ void enc_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) { hb[q][0] = split8(hid[q][0], hid[q][1], one); hb[q][1] = split8(hid[q][2], hid[q][3], one); }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
+            const int un = 8 * h + 4 + mt;
             f32x4 t[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) t[q] = X[q][mt];
-            load_unit_h<true>(ring[(mt + 3) & 3], wf);
-            wf += UF;
+            if (un < 15) load_unit_h<true>(ring[(un + 1) & 1], wl + (un + 1) * UF);
             SB_GEMM();
-            mm_unit_h<NQ>(t, ring[mt & 3], hb);
+            mm_unit_h<NQ>(t, ring[un & 1], hb);
             SB_GEMM();
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
         }
     }
-    DIAG_STAMP(5);
-    layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
-    DIAG_STAMP(6);
 }

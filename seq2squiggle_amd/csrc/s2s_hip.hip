@@ -19,6 +19,9 @@
 #include <vector>
 
 // ================================================================================ frontend
+// The frontend of a chunk is run by ONE wave (T = 16: every chunk is a single time tile and a sequence of its own): embedding,
+// pre-net, the three heads and the dwell source, encoder blocks.  Two chunks per wave (f16x3) give the in-order wave two
+// independent dependency chains to interleave; the eight waves of the workgroup work side by side on different chunks.
 template <int NQ>
 __device__ __forceinline__ void relu_tiles(f32x4 (&x)[NQ][4]) {
 #pragma unroll
@@ -29,47 +32,9 @@ __device__ __forceinline__ void relu_tiles(f32x4 (&x)[NQ][4]) {
             for (int r = 0; r < 4; ++r) x[q][mt][r] = fmaxf(x[q][mt][r], 0.0f);
 }
 
-// Linear(64,64)+ReLU+Linear(64,1)+Softplus on emb_out (modules.py:267-278, 182-195), NQ time tiles.
-template <int MODE, int NQ>
-__device__ __forceinline__ void mlp_head(const float* __restrict__ W, const MlpOff m, const f32x4 (&s)[NQ][4],
-                                         const HL (&sb)[NQ][2], int lane, float (&out)[NQ]) {
-    const int g = lane >> 4;
-    f32x4 hid[NQ][4];
-    if (MODE == 1) {
-        linear64_h<NQ>(W + m.w0h, W + m.b0, lane, sb, hid);
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 b = ldg4(W + m.b0 + 16 * mt + 4 * g);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) hid[q][mt] = b;
-        }
-        gemm_acc<NQ, 4, 4>(W + m.w0, lane, hid, s);
-    }
-    relu_tiles<NQ>(hid);
-    f32x4 w[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) w[mt] = ldg4(W + m.w3 + 16 * mt + 4 * g);
-    const float b3 = W[m.b3];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        float part = 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part += hid[q][mt][r] * w[mt][r];
-        out[q] = softplus_t(sum_g(part) + b3);
-    }
-}
-
 __device__ __forceinline__ int base_code(unsigned char ch) {       // utils.py:74 letter_to_int
     return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'T' ? 4 : ch == '_' ? 0 : -1;
 }
-
-// LDS one wave needs for the encoder blocks of its NQ chunks
-template <int MODE, int NQ> struct FrontLds {
-    static constexpr int BYTES = (MODE == 1) ? AttnLdsH<NQ, 1, 1, (NQ > 1)>::BYTES : AttnLds<1>::BYTES;
-};
 
 // One chunk as the frontend sees it.  bp: its 16+k-1 bases; inj_g / inj_zdw: its 16 injected variates (or null); slot: where
 // the decoder picks it up -- enc_out [16][64], sigma [16] at +1024, dur [16] (int32) at +1040; out_dur: the caller's [16] row;
@@ -87,38 +52,19 @@ struct FrontChunk {
 };
 #define S2S_SLOT_FLOATS S2S_PF_FLOATS
 
-// The frontend of NQ chunks, run by ONE wave (T = 16: every chunk is a single time tile and a sequence of its own): embedding,
-// pre-net, encoder blocks, the three heads and the dwell source.  `lds_raw`: FrontLds<MODE, NQ>::BYTES owned by this wave.
-// Two chunks per wave halve the weight bytes the wave pulls through the vector L1 per chunk and give the in-order wave two
-// independent dependency chains to interleave.
-template <int MODE, int NQ>   // 0: f32-input MFMA (NQ = 1), 1: split-f16 (s2s_device_h.h)
-__device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* __restrict__ W, const FrontChunk (&io)[NQ],
-                                                const ParamsDev& P, char* __restrict__ lds_raw, const DebugDev& dbg,
-                                                const int lane, const float one) {
-    static_assert(MODE == 1 || NQ == 1, "the f32 block has no per-tile sequences");
-    float* lds = reinterpret_cast<float*>(lds_raw);
+// ---- src_emb on the one-hot k-mer == bias + sum of k gathered columns of W_emb, then ReLU (modules.py:70-73)
+template <int NQ>
+__device__ __forceinline__ void front_embed(const ModelDev& M, const float* __restrict__ W, const FrontChunk (&io)[NQ], const int lane,
+                                            f32x4 (&X)[NQ][4]) {
     const int g = lane >> 4, c = lane & 15;
-    const int k = M.k;
-#ifdef S2S_DIAG
-    unsigned long long* diag_buf = dbg.diag ? dbg.diag + 32 : nullptr;
-    unsigned long long* diag_blk = dbg.diag ? dbg.diag + 16 : nullptr;
-#else
-    unsigned long long* diag_blk = nullptr;
-#endif
-    DIAG_DECL;
-
-    // ---- src_emb on the one-hot k-mer == bias + sum of k gathered columns of W_emb (modules.py:70-73)
-    f32x4 X[NQ][4];
-    {
-        f32x4 eb[4];
+    f32x4 eb[4];
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) eb[ft] = ldg4(W + M.emb_b + 16 * ft + 4 * g);
+    for (int ft = 0; ft < 4; ++ft) eb[ft] = ldg4(W + M.emb_b + 16 * ft + 4 * g);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft) X[q][ft] = eb[ft];
-    }
-    for (int j = 0; j < k; ++j) {
+        for (int ft = 0; ft < 4; ++ft) X[q][ft] = eb[ft];
+    for (int j = 0; j < M.k; ++j) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int code = (c < io[q].nv) ? base_code(io[q].bp[c + j]) : 0;   // pad k-mer = "_" * k (utils.py:342-347)
@@ -131,83 +77,48 @@ __device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* 
         }
     }
     relu_tiles<NQ>(X);
-    DIAG_STAMP(0);
-#pragma unroll 1
-    for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
-        f32x4 Y[NQ][4];
-        if (MODE == 1) {
-            HL xb[NQ][2];
+}
+
+// ---- second layer of a head: Linear(64,1) + Softplus on the ReLU'd hidden tile (modules.py:267-278, 182-195)
+template <int NQ>
+__device__ __forceinline__ void head_out(const float* __restrict__ W, const MlpOff m, f32x4 (&hid)[NQ][4], const int lane, float (&out)[NQ]) {
+    const int g = lane >> 4;
+    relu_tiles<NQ>(hid);
+    f32x4 w[4];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
-            linear64_h<NQ>(W + M.pre_wh[i], W + M.pre_b[i], lane, xb, Y);
-        } else {
+    for (int mt = 0; mt < 4; ++mt) w[mt] = ldg4(W + m.w3 + 16 * mt + 4 * g);
+    const float b3 = W[m.b3];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4 b = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
+    for (int q = 0; q < NQ; ++q) {
+        float part = 0.0f;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) Y[q][mt] = b;
-            }
-            gemm_acc<NQ, 4, 4>(W + M.pre_w[i], lane, Y, X);
-        }
-        relu_tiles<NQ>(Y);
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) X[q][mt] = Y[q][mt];
+            for (int r = 0; r < 4; ++r) part += hid[q][mt][r] * w[mt][r];
+        out[q] = softplus_t(sum_g(part) + b3);
     }
-    f32x4 S[NQ][4];                                                  // emb_out
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-        const f32x4 pe = ldg4(W + M.pe_enc + c * 64 + 16 * ft + 4 * g);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            S[q][ft] = X[q][ft];
-            X[q][ft] += pe;                                          // modules.py:80
-        }
-    }
-    if (dbg.emb_out) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            if (io[q].live)
-#pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
-                    *reinterpret_cast<f32x4*>(dbg.emb_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = S[q][ft];
-    }
-    HL Sb[NQ][2];                                                    // emb_out as a B operand for the three heads
-    if (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { Sb[q][0] = split8(S[q][0], S[q][1], one); Sb[q][1] = split8(S[q][2], S[q][3], one); }
-    }
-    // ---- the three heads read emb_out only (modules.py:275-278, 197-225), so they run BEFORE the encoder blocks: emb_out is
-    //      dead by then instead of being carried (and spilled) through them.
-    //      NoiseSampler: every lane group holds the heads' values of all tiles (sum_g is an all-reduce), so lane group q
-    //      finishes chunk q: ONE pass of the dwell sampler per wave.
-    DIAG_STAMP(1);
-    float sig[NQ];
-    mlp_head<MODE, NQ>(W, M.noise, S, Sb, lane, sig);
-    float sigma = sig[0];
+}
+
+// ---- the dwell source (modules.py:396-438) and the sigma / dur stores, given the heads' values.  Every lane group holds the
+//      heads' values of all tiles (sum_g is an all-reduce), so lane group q finishes chunk q: ONE pass of the sampler per wave.
+template <int NQ>
+__device__ __forceinline__ void front_dwell(const FrontChunk (&io)[NQ], const ParamsDev& P, const float (&sig)[NQ], const float (&cq)[NQ],
+                                            const float (&rq)[NQ], const DebugDev& dbg, const int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    float sigma = sig[0], conc = cq[0], rate = rq[0];
     FrontChunk me = io[0];
 #pragma unroll
     for (int q = 1; q < NQ; ++q)
-        if (g == q) { sigma = sig[q]; me = io[q]; }
+        if (g == q) { sigma = sig[q]; conc = cq[q]; rate = rq[q]; me = io[q]; }
     const bool mine = g < NQ && me.live;
     if (mine) {
         me.slot[1024 + c] = sigma;
         if (dbg.sigma) dbg.sigma[me.dbg_idx * 16 + c] = sigma;
     }
-    // ---- dwell source (modules.py:396-438)
     float gv;
     if (P.duration_sampling) {
-        float cq[NQ], rq[NQ];
-        mlp_head<MODE, NQ>(W, M.conc, S, Sb, lane, cq);
-        mlp_head<MODE, NQ>(W, M.rate, S, Sb, lane, rq);
-        float conc = cq[0], rate = rq[0];
-#pragma unroll
-        for (int q = 1; q < NQ; ++q)
-            if (g == q) { conc = cq[q]; rate = rq[q]; }
         conc = fmaxf(conc, 1e-8f);                                   // modules.py:215-216
         rate = fmaxf(rate, 1e-8f);                                   // modules.py:217-218
-        DIAG_STAMP(4);
         if (mine) {
             if (dbg.conc) dbg.conc[me.dbg_idx * 16 + c] = conc;
             if (dbg.rate) dbg.rate[me.dbg_idx * 16 + c] = rate;
@@ -240,26 +151,136 @@ __device__ __forceinline__ void frontend_chunks(const ModelDev& M, const float* 
         store_stream(me.out_dur + c, (int)rd);
         if (dbg.g) dbg.g[me.dbg_idx * 16 + c] = gv;
     }
-    DIAG_STAMP(5);
-#pragma unroll 1
-    for (int l = 0; l < M.enc_layers; ++l) {
-        if constexpr (MODE == 1) enc_block_h<NQ>(W, M.enc[l], X, lane, one, diag_blk);
-        else                     fft_block<1, 1, 16>(W, M.enc[l], X, lds, 0, lane, diag_blk);
-    }
-    DIAG_STAMP(2);
+}
+
+// X -> the chunks' hand-off slots (enc = true: enc_out) and, for the tests, the debug array of that stage (emb_out / enc_out)
+template <int NQ>
+__device__ __forceinline__ void front_store(const FrontChunk (&io)[NQ], const DebugDev& dbg, const f32x4 (&X)[NQ][4], const int lane,
+                                            const bool enc) {
+    const int g = lane >> 4, c = lane & 15;
+    float* const dbg_dst = enc ? dbg.enc_out : dbg.emb_out;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (!io[q].live) continue;
+        if (enc) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(io[q].slot + c * 64 + 16 * ft + 4 * g) = X[q][ft];
-        if (dbg.enc_out) {
+            for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(io[q].slot + c * 64 + 16 * ft + 4 * g) = X[q][ft];
+        }
+        if (dbg_dst) {
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
-                *reinterpret_cast<f32x4*>(dbg.enc_out + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = X[q][ft];
+                *reinterpret_cast<f32x4*>(dbg_dst + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g) = X[q][ft];
         }
     }
+}
 
-    DIAG_STAMP(3);
+// ---- f32 mode: one chunk per wave, every product on the f32-input MFMA, weights as f32 fragments from L2, encoder K/V in the
+//      wave's own slice of LDS (AttnLds<1>)
+struct FrontLdsF32 { static constexpr int BYTES = AttnLds<1>::BYTES; };
+__device__ __forceinline__ void frontend_f32(const ModelDev& M, const float* __restrict__ W, const FrontChunk (&io)[1],
+                                             const ParamsDev& P, char* __restrict__ lds_raw, const DebugDev& dbg, const int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 X[1][4];
+    front_embed<1>(M, W, io, lane, X);
+#pragma unroll 1
+    for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
+        f32x4 Y[1][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) Y[0][mt] = ldg4(W + M.pre_b[i] + 16 * mt + 4 * g);
+        gemm_acc<1, 4, 4>(W + M.pre_w[i], lane, Y, X);
+        relu_tiles<1>(Y);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) X[0][mt] = Y[0][mt];
+    }
+    front_store<1>(io, dbg, X, lane, false);                // emb_out (debug only)
+    float sig[1], cq[1] = {1.0f}, rq[1] = {1.0f};
+    auto head = [&](const MlpOff m, float (&out)[1]) {
+        f32x4 hid[1][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) hid[0][mt] = ldg4(W + m.b0 + 16 * mt + 4 * g);
+        gemm_acc<1, 4, 4>(W + m.w0, lane, hid, X);
+        head_out<1>(W, m, hid, lane, out);
+    };
+    head(M.noise, sig);                                              // modules.py:275-278
+    if (P.duration_sampling) { head(M.conc, cq); head(M.rate, rq); }
+    front_dwell<1>(io, P, sig, cq, rq, dbg, lane);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) X[0][ft] += ldg4(W + M.pe_enc + c * 64 + 16 * ft + 4 * g);   // modules.py:80
+#pragma unroll 1
+    for (int l = 0; l < M.enc_layers; ++l) fft_block<1, 1, 16>(W, M.enc[l], X, reinterpret_cast<float*>(lds_raw), 0, lane);
+    front_store<1>(io, dbg, X, lane, true);
+}
+
+// ---- f16x3: two chunks per wave, every product as three f16 MFMA terms, weights as f16 hi/lo units from L2, encoder attention
+//      in registers (s2s_device_h.h: enc_attention_h) -- no LDS at all.  (Measured: the phase is bound by its instruction count,
+//      about 6 k per chunk, like the decoder's; where the weights come from -- eight copies through the vector L1, or one copy
+//      staged in LDS behind ten barriers per group -- made no difference to its 71 us per 16 chunks.)
+template <int NQ>
+__device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __restrict__ W, const FrontChunk (&io)[NQ],
+                                             const ParamsDev& P, const DebugDev& dbg, const int lane, const float one) {
+    const int g = lane >> 4, c = lane & 15;
+#ifdef S2S_DIAG
+    unsigned long long* diag_buf = dbg.diag ? dbg.diag + 32 : nullptr;
+#endif
+    DIAG_DECL;
+    f32x4 X[NQ][4];
+    front_embed<NQ>(M, W, io, lane, X);
+    DIAG_STAMP(0);
+#pragma unroll 1
+    for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
+        HL xb[NQ][2];
+        f32x4 Y[NQ][4];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { xb[q][0] = split8(X[q][0], X[q][1], one); xb[q][1] = split8(X[q][2], X[q][3], one); }
+        linear64_h<NQ>(W + M.pre_wh[i], W + M.pre_b[i], lane, xb, Y);
+        relu_tiles<NQ>(Y);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) X[q][mt] = Y[q][mt];
+    }
+    front_store<NQ>(io, dbg, X, lane, false);                        // emb_out (debug only)
+    DIAG_STAMP(1);
+    {   // the three heads read emb_out only (modules.py:275-278, 197-225), so they run BEFORE the encoder blocks: emb_out is dead
+        // by then instead of being carried (and spilled) through them
+        HL Sb[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { Sb[q][0] = split8(X[q][0], X[q][1], one); Sb[q][1] = split8(X[q][2], X[q][3], one); }
+        float sig[NQ], cq[NQ], rq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { cq[q] = 1.0f; rq[q] = 1.0f; }
+        auto head = [&](const MlpOff m, float (&out)[NQ]) {
+            f32x4 hid[NQ][4];
+            linear64_h<NQ>(W + m.w0h, W + m.b0, lane, Sb, hid);
+            head_out<NQ>(W, m, hid, lane, out);
+        };
+        head(M.noise, sig);
+        if (P.duration_sampling) { head(M.conc, cq); head(M.rate, rq); }
+        DIAG_STAMP(4);
+        front_dwell<NQ>(io, P, sig, cq, rq, dbg, lane);
+    }
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 pe = ldg4(W + M.pe_enc + c * 64 + 16 * ft + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) X[q][ft] += pe;                 // modules.py:80
+    }
+    DIAG_STAMP(5);
+#pragma unroll 1
+    for (int l = 0; l < M.enc_layers; ++l) {
+        const LayerOff L = M.enc[l];
+        const float* const wl = W + L.stream_h;                      // pack_layer: units 0-15 attention, 16-47 FFN
+        f32x4 acc[NQ][4];
+        HL x1b[NQ][2];
+        enc_attention_h<NQ>(W, L, wl, X, acc, lane, one);
+        DIAG_STAMP(2);
+        enc_ffn_begin_h<NQ>(W, L, acc, X, x1b, lane, one);
+        enc_ffn_half_h<NQ>(W, L, wl + 16 * 1024, 0, x1b, X, lane, one);
+        enc_ffn_half_h<NQ>(W, L, wl + 32 * 1024, 2, x1b, X, lane, one);
+        layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+        DIAG_STAMP(3);
+    }
+    front_store<NQ>(io, dbg, X, lane, true);
 }
 
 // ================================================================================ decoder
@@ -412,7 +433,7 @@ template <int MODE> struct Fused {
     static constexpr bool PF = (MODE == 1);                       // next chunk's slot prefetched into LDS (dec_blocks)
     static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (PF ? S2S_SLOT_FLOATS * 4 : 0);
     static_assert(LDS <= 160 * 1024, "LDS per workgroup");
-    static_assert(DEC_WAVES * FrontLds<FMODE, FNQ>::BYTES <= LDS, "the frontend waves' K/V images share the decoder's LDS");
+    static_assert(FMODE == 1 || DEC_WAVES * FrontLdsF32::BYTES <= LDS, "the f32 frontend waves' K/V images share the decoder's LDS");
 };
 #define S2S_MAX_GROUP (2 * DEC_WAVES)
 // TEST = false is the production instance: no injected variates and no stage outputs, whose address arithmetic would otherwise
@@ -446,7 +467,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
 #endif
         DIAG_DECL;
         __syncthreads();                   // the previous group's last block is done with the K/V region and with the slots
-        if (F::FNQ * wave < n_here) {
+        {
             FrontChunk io[F::FNQ];
 #pragma unroll
             for (int q = 0; q < F::FNQ; ++q) {
@@ -460,7 +481,10 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
             }
             int lnf = lane;                // (opaque per group, like `ln` below: nothing lane-dependent is hoisted out of the loops and spilled)
             asm volatile("" : "+v"(lnf));
-            frontend_chunks<F::FMODE, F::FNQ>(M, W, io, P, lds_raw + wave * FrontLds<F::FMODE, F::FNQ>::BYTES, dbg, lnf, one);
+            if (F::FNQ * wave < n_here) {
+                if constexpr (F::FMODE == 1) frontend_h16<F::FNQ>(M, W, io, P, dbg, lnf, one);
+                else                         frontend_f32(M, W, io, P, lds_raw + wave * FrontLdsF32::BYTES, dbg, lnf);
+            }
         }
         __syncthreads();                   // the group's slots are written (global stores: workgroup-scope release/acquire)
         DIAG_STAMP(7);                     // frontend phase and its two barriers
@@ -473,7 +497,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         }
         DIAG_STAMP(8);
 #pragma unroll 1
-        for (int j = 0; j < n_here; ++j) {
+        for (int j = 0; j < ((S2S_ABL & 65536) ? 0 : n_here); ++j) {      // (65536: timing of the frontend phase alone)
             const int b = g0 + j;
             // (after the group's last chunk everything "next" is that chunk again, computed and thrown away: no branches here,
             // the register allocator spills values that live from one conditional block to another)

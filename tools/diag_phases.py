@@ -21,10 +21,8 @@ for it in range(2):
     eng.predict_chunks(b, n, S.PredictParams(seed=1))
     _lib.lib().s2s_diag_read(eng._h, out)
 v = list(out)
-front = {32: "frontend: embedding gather", 33: "frontend: pre-net, + PE", 34: "frontend: encoder blocks", 35: "frontend: enc_out stores",
-         36: "frontend: three heads", 37: "frontend: dwell sampler, stores",
-         16: "  enc block: entry", 17: "  enc block: K/V GEMM + LDS store", 18: "  enc block: sync", 19: "  enc block: attention (Q, S, softmax, PV, fc)",
-         20: "  enc block: LN1", 21: "  enc block: FFN", 22: "  enc block: LN2"}
+front = {32: "frontend: embedding gather", 33: "frontend: pre-net", 36: "frontend: three heads", 37: "frontend: dwell sampler, stores, + PE",
+         34: "frontend: encoder attention (K/V/Q, softmax, PV, fc)", 35: "frontend: encoder LN1 + FFN + LN2"}
 names = {7: "frontend phase + its two barriers (fused kernel)", 0: "entry barrier wait", 1: "K/V GEMM + LDS store", 2: "barrier 2 wait", 3: "attention (Q, S, softmax, PV, fc)",
          4: "LN1 (+ FFN fill issue, operand split)", 5: "FFN", 6: "LN2", 8: "prologue (LR gather)", 9: "epilogue",
          12: "barrier: attention done (FFN_LDS)", 13: "wait: FFN weights landed", 14: "barrier: weights visible", 15: "blocks total"}
