@@ -468,22 +468,27 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         DIAG_DECL;
         __syncthreads();                   // the previous group's last block is done with the K/V region and with the slots
         {
-            FrontChunk io[F::FNQ];
-#pragma unroll
-            for (int q = 0; q < F::FNQ; ++q) {
-                const int j = F::FNQ * wave + q;
-                const bool live = j < n_here;
-                const int b = g0 + (live ? j : F::FNQ * wave);       // a filler repeats the wave's first chunk
-                io[q] = FrontChunk{chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb, n_valid[b],
-                                   (unsigned long long)(first_chunk + b), inj_g ? inj_g + (size_t)b * 16 : nullptr,
-                                   inj_zdw ? inj_zdw + (size_t)b * 16 : nullptr, slot0 + j * S2S_SLOT_FLOATS,
-                                   out_dur + (size_t)b * 16, dbg_base + b, live};
-            }
             int lnf = lane;                // (opaque per group, like `ln` below: nothing lane-dependent is hoisted out of the loops and spilled)
             asm volatile("" : "+v"(lnf));
-            if (F::FNQ * wave < n_here) {
-                if constexpr (F::FMODE == 1) frontend_h16<F::FNQ>(M, W, io, P, dbg, lnf, one);
-                else                         frontend_f32(M, W, io, P, lds_raw + wave * FrontLdsF32::BYTES, dbg, lnf);
+            auto chunk_of = [&](const int j, const int j_filler) {
+                const bool live = j < n_here;
+                const int b = g0 + (live ? j : j_filler);            // a filler repeats the wave's first chunk
+                return FrontChunk{chunk_start ? bases + chunk_start[b] : bases + (size_t)b * nb, n_valid[b],
+                                  (unsigned long long)(first_chunk + b), inj_g ? inj_g + (size_t)b * 16 : nullptr,
+                                  inj_zdw ? inj_zdw + (size_t)b * 16 : nullptr, slot0 + j * S2S_SLOT_FLOATS,
+                                  out_dur + (size_t)b * 16, dbg_base + b, live};
+            };
+            if constexpr (F::FMODE == 1) {
+                if (n_here > DEC_WAVES) {                            // two chunks per wave
+                    const FrontChunk io[2] = {chunk_of(2 * wave, 2 * wave), chunk_of(2 * wave + 1, 2 * wave)};
+                    if (2 * wave < n_here) frontend_h16<2>(M, W, io, P, dbg, lnf, one);
+                } else {                                             // a short group (small batches): one chunk per wave, more waves busy
+                    const FrontChunk io[1] = {chunk_of(wave, 0)};
+                    if (wave < n_here) frontend_h16<1>(M, W, io, P, dbg, lnf, one);
+                }
+            } else {
+                const FrontChunk io[1] = {chunk_of(wave, 0)};
+                if (wave < n_here) frontend_f32(M, W, io, P, lds_raw + wave * FrontLdsF32::BYTES, dbg, lnf);
             }
         }
         __syncthreads();                   // the group's slots are written (global stores: workgroup-scope release/acquire)
