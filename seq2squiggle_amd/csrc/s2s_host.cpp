@@ -117,6 +117,8 @@ class Pool {
 
 std::mutex g_pool_mutex;          // one batch at a time (the writers call from a single writer thread anyway)
 Pool* g_pool = nullptr;
+std::vector<std::vector<uint8_t>> g_scratch;   // per worker: the uncompressed body of the record it is on (kept between calls:
+                                               // fresh pages every batch cost more than the compression of a small one)
 
 }  // namespace
 
@@ -137,7 +139,8 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
     if (method == 2 && !zstd().ok) return S2S_ERR_ARG;
     if (n == 0) return 0;
     std::lock_guard<std::mutex> guard(g_pool_mutex);
-    if (!g_pool || g_pool->size() != threads) { delete g_pool; g_pool = new Pool(threads); }
+    if (!g_pool || g_pool->size() < threads) { delete g_pool; g_pool = new Pool(threads); }   // grows, never shrinks
+    const int workers = g_pool->size();
 
     // slot i of `out`: room for record i's worst case, so that workers never wait for each other; compacted afterwards
     std::vector<int64_t> slot(n + 1), size(n);
@@ -148,8 +151,9 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
     }
     if (slot[n] > capacity) return S2S_ERR_ARG;
     std::atomic<int> failed{0};
-    std::vector<std::vector<uint8_t>> scratch(threads);
-    std::vector<void*> defl(threads, nullptr);
+    if ((int)g_scratch.size() < workers) g_scratch.resize(workers);
+    std::vector<std::vector<uint8_t>>& scratch = g_scratch;
+    std::vector<void*> defl(workers, nullptr);
     const bool use_deflate = method == 1 && deflate().ok;
     g_pool->run(n, [&](int i, int w) {
         const int64_t np = prefix_offs[i + 1] - prefix_offs[i], ns = signal_offs[i + 1] - signal_offs[i], nx = suffix_offs[i + 1] - suffix_offs[i];

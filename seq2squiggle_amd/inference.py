@@ -261,7 +261,7 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     if saved_weights is None:
         raise FileNotFoundError("no model weights given: downloading released weights needs network access; pass "
                                 "--model <file.ckpt>")
-    first_chunk, first_read = 0, 0
+    first_chunk, first_read, total_l = 0, 0, 0
     if world > 1 and not seed:
         raise ValueError("multi-process runs need one seed for all ranks: pass an explicit --seed, or let the CLI share a "
                          "fresh one (parallel.shared_seed) before calling inference_run")
@@ -289,7 +289,7 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
             first_chunk, first_read = picked["first"], picked["lo"]
             logger.info(f"rank {rank}/{world}: {len(reads)} of {len(lens)} reads, first global chunk {first_chunk}")
         else:
-            reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len)
+            reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len, lazy=world == 1)
             if world > 1:                  # read mode: every rank parses the same file, then keeps its contiguous share
                 reads = list(reads)
                 lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]

@@ -112,6 +112,7 @@ class BLOW5Writer:
         self.binary = self.filename.endswith(".blow5")
         self.compress_level = 1               # zlib / zstd level of BLOW5 records; any level is a valid stream
         self.threads = min(64, len(os.sched_getaffinity(0)))    # compression threads (the reference: cpu_count)
+        self._out = None                      # packed records of the batch being written
 
     def start_at(self, read_index: int) -> None:
         """Rank shards (parallel.py): this writer's first read is read `read_index` of the whole job, so read ids and
@@ -275,8 +276,10 @@ class BLOW5Writer:
         total = int(head_offs[-1] + tail_offs[-1] + sig_offs[-1])
         L = lib()
         cap = int(L.s2s_blow5_pack_bound(total, n))
-        out = np.empty(cap, np.uint8)
-        threads = min(self.threads, max(1, n))
+        if self._out is None or self._out.size < cap:              # kept between batches: no fresh pages per call
+            self._out = np.empty(cap + cap // 4, np.uint8)
+        out = self._out
+        threads = self.threads
         got = L.s2s_blow5_pack(head.ctypes.data, head_offs.ctypes.data, tail.ctypes.data, tail_offs.ctypes.data, C.c_void_p(sig_ptr),
                                sig_offs.ctypes.data, n, self.RECORD_METHODS[self.record_compression], self.compress_level,
                                threads, out.ctypes.data, cap)

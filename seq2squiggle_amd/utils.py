@@ -202,7 +202,15 @@ def reverse_complement(f):
 
 def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20,
              materialise=None):
-    """Sample reads from the reference (utils.py:415-479).  The order of draws from the global `random`
+    """The whole read set as a list (the reference's return value); see sampling_iter."""
+    return list(sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, max_retries,
+                              materialise))
+
+
+def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20,
+                  materialise=None):
+    """Sample reads from the reference (utils.py:415-479), one at a time: the predict loop pulls reads as it packs batches,
+    so the GPU starts after the first batch's worth of draws instead of after all of them.  The order of draws from the global `random`
     stream (start position, strand, N replacement) and the per-(read, retry) scipy seed
     `seed + read_i * (max_retries + 1) + retries` are those of the reference, so a seed selects the same
     read set.
@@ -210,7 +218,7 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
     materialise = (lo, hi): only the accepted reads lo..hi-1 are built as strings, the others are returned as their
     LENGTH (an int) -- every draw is still made, so the stream and the read set are unchanged; a rank of a sharded run
     pays the string work (slice copy, reverse complement) only for its own reads."""
-    sampled_reads = []
+    n_accepted = 0
     total_genome_len = sum(genome_lens)
     # the first-try lengths of a block of reads in one vectorised pass (the per-seed scipy call costs ~100 us and is what
     # the reference's sampler spends its time in); retries and the other distributions go through scipy one by one
@@ -252,14 +260,14 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
             if got is None:
                 continue
             read, strand = got
-            if materialise is not None and not (materialise[0] <= len(sampled_reads) < materialise[1]):
-                sampled_reads.append(len(read))
+            if materialise is not None and not (materialise[0] <= n_accepted < materialise[1]):
+                yield len(read)
             else:
-                sampled_reads.append(reverse_complement(read) if strand == "-" else read)
+                yield reverse_complement(read) if strand == "-" else read
+            n_accepted += 1
             break
         else:
             logger.debug(f"Failed to sample a valid read after {max_retries} retries for read {read_i}. Skipping this read.")
-    return sampled_reads
 
 
 def yield_reads(reads):
@@ -301,8 +309,9 @@ def sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, m
 
 
 def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta, seed, save=False, distr="expon",
-                                profile="dna-r10-min", min_read_len=30):
-    """utils.py:495-582 (same argument checks and messages)."""
+                                profile="dna-r10-min", min_read_len=30, lazy=False):
+    """utils.py:495-582 (same argument checks and messages).  lazy: the reads come from a generator that samples while it is
+    being consumed, and the chunk count returned beside it is the estimate n * r / max_dna_len instead of the exact sum."""
     _check_sampling_args(n, r, c)
     total_len = sum(len(seq) for seq in genome_seqs)
     avg_genome_len = total_len / len(genome_seqs)
@@ -310,6 +319,9 @@ def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta
     if r > avg_genome_len and profile.startswith("dna"):
         logger.warning(f"Average reference sequence length ({avg_genome_len:.2f}) is smaller than the desired average "
                        f"read length ({r}). Reads longer than their reference sequence are skipped; consider a smaller -r.")
+    if lazy and not save:
+        return (yield_reads(sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len)),
+                round(seq_num * r / config["max_dna_len"]))
     read_list = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len)
     total_l = sum(round(len(read) / config["max_dna_len"]) for read in read_list)
     reads_fasta = export_fasta(read_list, fasta) if save else yield_reads(read_list)
@@ -333,8 +345,9 @@ def preprocess_genome(fasta: str):
     return list(seqs), list(lens)
 
 
-def get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len, save=False):
-    """-> (iterable of (sequence, read_id), approximate chunk count)  (utils.py:641-671)."""
+def get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len, save=False, lazy=False):
+    """-> (iterable of (sequence, read_id), approximate chunk count)  (utils.py:641-671).  lazy: reference mode samples while
+    the iterable is consumed."""
     logger.info(f"{'Read' if read_input else 'Reference'} mode.")
     is_rna = profile.startswith("rna")
     if read_input:
@@ -348,7 +361,7 @@ def get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read
         return ((seq, str(uuid4())) for seq, _ in sampled), effective
     genome_seqs, genome_lens = preprocess_genome(fasta)
     reads_fasta, total_l = sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, str(fasta), seed, save,
-                                                       distr, profile, min_read_len)
+                                                       distr, profile, min_read_len, lazy=lazy)
     return (read_fasta(reads_fasta, is_rna), total_l) if save else (reads_fasta, total_l)
 
 
