@@ -228,7 +228,7 @@ __device__ __forceinline__ void layer_norm64(f32x4 (&x)[NQ][4], const float* __r
 }
 
 // Barrier between the phases of a block that exchange K/V through LDS.  SOLO: the block's sequence is one time tile owned
-// by ONE wave (the encoder), so the exchange stays inside the wave -- LDS executes a wave's accesses in issue order, only the
+// by ONE wave (the f32 encoder), so the exchange stays inside the wave -- LDS executes a wave's accesses in issue order, only the
 // compiler has to keep them in program order -- and the block may run in some waves of a larger workgroup and not in others.
 template <bool SOLO>
 __device__ __forceinline__ void block_sync() {

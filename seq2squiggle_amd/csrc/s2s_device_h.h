@@ -308,7 +308,8 @@ __device__ __forceinline__ void load_unit_h(f32x4 (&f)[4], const float* __restri
     }
 }
 
-// One FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (NKT = 16 or 1 key tiles).
+// One DECODER FFTBlock (layers.py:116-142), same contract as fft_block in s2s_device.h (the f16x3 encoder has its own,
+// register-resident form at the end of this file).
 template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
@@ -500,7 +501,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
     // A weight unit feeds only 6*NQ MFMAs (~200 cycles) here, less than an L2 round trip, so the stream
     // runs three units ahead through a ring of four unit buffers (8 units per slice: slots repeat).
-    // (the one-wave frontend workgroups hide latency with occupancy instead: one unit ahead, 32 registers less)
+    // (a single-tile instantiation gets a two-deep ring: 32 registers less)
     constexpr int RD = (NQ >= 2) ? 4 : 2, RM = RD - 1;               // ring depth; units in flight = RD - 1
     f32x4 ring[RD][4];
     // FFN_LDS (the 8-wave decoder): every wave needs every FFN weight unit, and eight copies of the 128 KiB through the CU's
