@@ -206,6 +206,13 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
                        const uint8_t* signal, const int64_t* signal_offs, int32_t n_records, int32_t method, int32_t level,
                        int32_t threads, uint8_t* out, int64_t capacity);
 
+/* The same worker threads on plain byte rows: row i = in[in_offs[i] : in_offs[i+1]] is compressed on its own (method 1: zlib
+ * container, 2: one zstd frame -- the second stage of POD5's VBZ after s2s_svb_encode's svb16 stream, what pod5.Writer.add_reads
+ * runs per signal row, reference signal_io.py:268-282) and the results are laid back to back in `out` with their bounds in
+ * out_offs [n+1].  capacity >= s2s_blow5_pack_bound(total bytes, n) always suffices.  Returns the bytes written, or < 0. */
+int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n_rows, int32_t method, int32_t level,
+                          int32_t threads, uint8_t* out, int64_t capacity, int64_t* out_offs);
+
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): 48 per-phase wave-cycle sums since the
  * last call (0-15 decoder, 16-31 the encoder blocks of the frontend, 32-47 the frontend's own
  * phases; tools/diag_phases.py names them); S2S_ERR_ARG in a normal build. */

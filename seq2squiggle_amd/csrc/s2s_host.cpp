@@ -201,4 +201,56 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
     return pos;
 }
 
+int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n, int32_t method, int32_t level, int32_t threads,
+                          uint8_t* out, int64_t capacity, int64_t* out_offs) {
+    if (n < 0 || threads < 1 || !out_offs || (n > 0 && (!in || !in_offs || !out))) return S2S_ERR_ARG;
+    if (method != 1 && method != 2) return S2S_ERR_ARG;
+    if (method == 2 && !zstd().ok) return S2S_ERR_ARG;
+    out_offs[0] = 0;
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> guard(g_pool_mutex);
+    if (!g_pool || g_pool->size() < threads) { delete g_pool; g_pool = new Pool(threads); }
+    const int workers = g_pool->size();
+    std::vector<int64_t> slot(n + 1), size(n);
+    slot[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t len = in_offs[i + 1] - in_offs[i];
+        if (len < 0) return S2S_ERR_ARG;
+        slot[i + 1] = slot[i] + len + len / 128 + 1024;
+    }
+    if (slot[n] > capacity) return S2S_ERR_ARG;
+    std::atomic<int> failed{0};
+    std::vector<void*> defl(workers, nullptr);
+    const bool use_deflate = method == 1 && deflate().ok;
+    g_pool->run(n, [&](int i, int w) {
+        const uint8_t* src = in + in_offs[i];
+        const int64_t len = in_offs[i + 1] - in_offs[i], room = slot[i + 1] - slot[i];
+        uint8_t* dst = out + slot[i];
+        int64_t written = -1;
+        if (use_deflate) {
+            if (!defl[w]) defl[w] = deflate().alloc(level < 1 ? 1 : level);
+            const size_t r = defl[w] ? deflate().zlib_compress(defl[w], src, len, dst, room) : 0;
+            if (r) written = (int64_t)r;
+        } else if (method == 1) {
+            uLongf dl = (uLongf)room;
+            if (compress2(dst, &dl, src, (uLong)len, level) == Z_OK) written = (int64_t)dl;
+        } else {
+            const size_t r = zstd().compress(dst, room, src, len, level);
+            if (!zstd().is_error(r)) written = (int64_t)r;
+        }
+        if (written < 0) { failed = 1; written = 0; }
+        size[i] = written;
+    });
+    for (void* d : defl)
+        if (d) deflate().free_(d);
+    if (failed) return S2S_ERR_HIP;
+    int64_t pos = 0;
+    for (int i = 0; i < n; ++i) {                               // close the gaps, in row order
+        if (pos != slot[i]) std::memmove(out + pos, out + slot[i], size[i]);
+        pos += size[i];
+        out_offs[i + 1] = pos;
+    }
+    return pos;
+}
+
 }  // extern "C"

@@ -151,6 +151,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     staging = _STAGING.setdefault(str(dev), (_Staging(dev), _Staging(dev)))   # super-batch i + 2 reuses i's buffer: i has been collected by then
     n_launched = 0
 
+    gpu_rows = writer.gpu_signal_rows() if hasattr(writer, "gpu_signal_rows") else None   # (svb variant, samples per row) | None
+
     def launch(group):
         nonlocal total, n_launched
         mark("pack")
@@ -158,20 +160,48 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         B = int(read_first[-1])
         if B == 0:
             return None
+        arrays = [flat, chunk_start, n_valid, read_first]
+        if gpu_rows:
+            # candidate rows of the signal codec from the chunk counts (the stripped lengths are not known here): read r may
+            # need up to ceil(250 * chunks / row_samples) rows; those it turns out not to need come back empty
+            n_rows = -(-(np.diff(read_first).astype(np.int64) * 250) // gpu_rows[1])
+            row_read = np.repeat(np.arange(len(group), dtype=np.int32), n_rows)
+            row_index = (np.arange(int(n_rows.sum())) - np.repeat(np.cumsum(n_rows) - n_rows, n_rows)).astype(np.int32)
+            arrays += [row_read, row_index]
         mark("h2d+launch")
         # H2D from pinned staging on the copy stream: a pageable copy on the compute stream would hold this thread until
         # the previous super-batch's kernels have drained
-        ins = staging[n_launched % 2].upload((flat, chunk_start, n_valid, read_first), up_stream)
+        ins = staging[n_launched % 2].upload(arrays, up_stream)
         out = model.engine.predict_packed(ins[0], ins[1], ins[2], model._params(), first_global_chunk=model.chunks_done)
         model.chunks_done += B
         total += B
         n_launched += 1
         ex = model.engine.export_reads(out["signal"], ins[3], profile_dict["digitisation"], profile_dict["range"],
                                        profile_dict["offset_mean"], rna=rna, want_pa=False, want_dac=True)
+        names = [n for _, n in group]
+        main = torch.cuda.current_stream(dev)
+        if gpu_rows:
+            # the signal leaves the GPU StreamVByte-coded (~1.1-1.3 bytes per sample): the small tables first, the blob in
+            # collect() once its size is known
+            svb = model.engine.svb_encode(ex["dac"], ex["offsets"], ins[4], ins[5], gpu_rows[1], gpu_rows[0], B * 250)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                offs_h = torch.empty(ex["offsets"].shape, dtype=torch.int64, pin_memory=True)
+                rows_h = torch.empty(svb["offsets"].shape, dtype=torch.int64, pin_memory=True)
+                offs_h.copy_(ex["offsets"], non_blocking=True)
+                rows_h.copy_(svb["offsets"], non_blocking=True)
+                for t in (ex["offsets"], svb["offsets"], svb["out"]):
+                    t.record_stream(copy_stream)
+                done = torch.cuda.Event()
+                done.record(copy_stream)
+            mark("launched")
+            return names, offs_h, (rows_h, svb["out"], row_read), done
         # D2H on its own stream, so that it runs beside the next super-batch's kernels instead of queueing behind them.
         # The whole capacity is copied (its size is known without a sync; 16 MB per 32 k chunks) into pinned memory.
         ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))
+        ready.record(main)
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ready)
             offs_h = torch.empty(ex["offsets"].shape, dtype=torch.int64, pin_memory=True)
@@ -183,17 +213,25 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             done = torch.cuda.Event()
             done.record(copy_stream)
         mark("launched")
-        return [n for _, n in group], offs_h, dac_h, done
+        return names, offs_h, dac_h, done
 
     def collect(job):
         nonlocal pending
-        ids, offs_h, dac_h, done = job
+        ids, offs_h, payload, done = job
         mark("wait d2h")
         done.synchronize()
         mark("records")
         offs = offs_h.numpy()
-        dac = dac_h.numpy()[: int(offs[-1])]
-        recs = writer.dac_records(ids, dac, offs)
+        if gpu_rows:
+            rows_h, blob_d, row_read = payload
+            row_offs = rows_h.numpy()
+            with torch.cuda.stream(copy_stream):          # the blob, now that its size is known (the kernels are long done)
+                blob_h = torch.empty(int(row_offs[-1]), dtype=torch.uint8, pin_memory=True)
+                blob_h.copy_(blob_d[: int(row_offs[-1])], non_blocking=True)
+            copy_stream.synchronize()
+            recs = writer.svb_records(ids, offs, row_read, row_offs, blob_h.numpy())
+        else:
+            recs = writer.dac_records(ids, payload.numpy()[: int(offs[-1])], offs)
         mark("wait writer")
         if pending is not None:
             pending.result()

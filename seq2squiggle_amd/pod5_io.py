@@ -170,12 +170,12 @@ def _signal_schema(pa, meta, vbz=True):
 
 
 def _signal_batch(pa, schema, rows, vbz=True):
-    """rows: (read_id bytes, int16 array [, VBZ bytes already made]) per signal-table row."""
-    counts = [len(r[1]) for r in rows]
+    """rows: (read_id bytes, int16 array or None, VBZ bytes or None, sample count) per signal-table row."""
+    counts = [r[3] for r in rows]
     ids = pa.array([r[0] for r in rows], pa.binary(16))
     if vbz:
         from .codecs import vbz_compress
-        blobs = [r[2] if len(r) > 2 and r[2] is not None else vbz_compress(r[1]) for r in rows]
+        blobs = [r[2] if r[2] is not None else vbz_compress(r[1]) for r in rows]
         return pa.record_batch([ids, pa.array(blobs, pa.large_binary()), pa.array(counts, pa.uint32())], schema=schema)
     flat = np.concatenate([r[1] for r in rows]) if rows else np.zeros(0, np.int16)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -273,18 +273,31 @@ class Pod5FileWriter:
         self.closed = False
 
     def add_reads(self, reads: Sequence[dict]) -> None:
+        """A read carries its samples as `signal` (int16), or -- from the GPU codec path -- as `vbz_rows`: the finished VBZ blob
+        and sample count of each of its signal-table rows (SIGNAL_CHUNK samples per row) plus `num_samples`."""
         for r in reads:
-            raw = np.ascontiguousarray(r["signal"], dtype=np.int16)
             rows = []
-            for lo in range(0, max(len(raw), 1), SIGNAL_CHUNK):
-                rows.append(self._n_rows)
-                self._pending.append((r["read_id"].bytes, raw[lo: lo + SIGNAL_CHUNK]))
-                self._n_rows += 1
+            if r.get("vbz_rows") is not None:
+                if not self.vbz:
+                    raise ValueError("precompressed rows need signal_compression='vbz'")
+                n_samples = int(r["num_samples"])
+                for blob, count in r["vbz_rows"]:
+                    rows.append(self._n_rows)
+                    self._pending.append((r["read_id"].bytes, None, blob, int(count)))
+                    self._n_rows += 1
+            else:
+                raw = np.ascontiguousarray(r["signal"], dtype=np.int16)
+                n_samples = len(raw)
+                for lo in range(0, max(len(raw), 1), SIGNAL_CHUNK):
+                    rows.append(self._n_rows)
+                    piece = raw[lo: lo + SIGNAL_CHUNK]
+                    self._pending.append((r["read_id"].bytes, piece, None, len(piece)))
+                    self._n_rows += 1
             self._rows_of.append(rows)
             if r["run_info"]["acquisition_id"] not in self._run_ids:
                 self._run_ids.append(r["run_info"]["acquisition_id"])
                 self._run_infos.append(r["run_info"])
-            self._reads.append({k: v for k, v in r.items() if k != "signal"} | {"num_samples": len(raw)})
+            self._reads.append({k: v for k, v in r.items() if k not in ("signal", "vbz_rows")} | {"num_samples": n_samples})
         while len(self._pending) >= SIGNAL_BATCH_ROWS:
             self._sig_writer.write_batch(_signal_batch(self.pa, self._sig_schema, self._pending[:SIGNAL_BATCH_ROWS], self.vbz))
             del self._pending[:SIGNAL_BATCH_ROWS]

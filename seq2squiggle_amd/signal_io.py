@@ -147,8 +147,10 @@ class BLOW5Writer:
         return "\n".join(lines) + "\n"
 
     # ------------------------------------------------------------------ records
-    def _record(self, read_id, raw):
-        """One record as the reference builds it (signal_io.py:123-161)."""
+    def _record(self, read_id, raw, n_samples=None):
+        """One record as the reference builds it (signal_io.py:123-161).  n_samples: the read's length when `raw` is not
+        carried (the samples arrive compressed, svb_records)."""
+        n_samples = len(raw) if n_samples is None else n_samples
         if self.ideal_mode:
             median_before_value, offset_value = self.median_before, self.offset
         else:
@@ -157,10 +159,10 @@ class BLOW5Writer:
         self.n_written += 1
         rid = read_id if self.preserve_read_ids else indexed_uuid(self.n_written)
         rec = {"read_id": str(rid), "read_group": 0, "digitisation": self.digitisation, "offset": offset_value,
-               "range": self.signal_range, "sampling_rate": self.sample_rate, "len_raw_signal": len(raw),
+               "range": self.signal_range, "sampling_rate": self.sample_rate, "len_raw_signal": n_samples,
                "signal": raw, "channel_number": "0", "median_before": median_before_value,
                "read_number": self.n_written - 1, "start_mux": 0, "start_time": self.start_time}
-        self.start_time += len(raw)
+        self.start_time += n_samples
         return rec
 
     def records(self):
@@ -190,6 +192,25 @@ class BLOW5Writer:
     def write_records(self, recs) -> None:
         """Append already-built records; safe to call from one background thread at a time."""
         self._write(recs)
+
+    def gpu_signal_rows(self):
+        """(StreamVByte variant, samples per row) when the streaming path should encode the signal on the GPU
+        (s2s_svb_encode) instead of handing over int16 samples: svb-zd BLOW5 = one 32-bit-variant blob per read."""
+        return (32, 1 << 40) if self.binary and self.signal_compression == "svb-zd" else None
+
+    def svb_records(self, read_ids, offsets, row_read, row_offsets, blob) -> list:
+        """dac_records() for reads whose samples arrive as svb-zd blobs: row i (read row_read[i]) is
+        blob[row_offsets[i]:row_offsets[i+1]]; a read with no samples has an empty blob and is skipped."""
+        recs = []
+        for i in range(len(row_read)):
+            r = int(row_read[i])
+            n = int(offsets[r + 1] - offsets[r])
+            if n <= 0:
+                continue
+            rec = self._record(read_ids[r], np.zeros(0, np.int16), n_samples=n)
+            rec["svb"] = blob[row_offsets[i]:row_offsets[i + 1]]
+            recs.append(rec)
+        return recs
 
     def save(self):
         if self.signals is None:
@@ -228,7 +249,9 @@ class BLOW5Writer:
         rid, ch = r["read_id"].encode(), r["channel_number"].encode()
         if self.signal_compression == "svb-zd":
             from .codecs import svb_zd_compress
-            sig = r.get("svb") or svb_zd_compress(np.ascontiguousarray(r["signal"]).astype("<i2"))
+            sig = r.get("svb")
+            if sig is None:
+                sig = svb_zd_compress(np.ascontiguousarray(r["signal"]).astype("<i2"))
             sig = np.frombuffer(sig, dtype=np.uint8)
             n_field = sig.size
         else:
@@ -460,7 +483,63 @@ class POD5Writer:
                 recs.append(self._record(idx, rid, dac[offsets[i]:offsets[i + 1]], self._stream_run_info))
         return recs
 
+    def gpu_signal_rows(self):
+        """(StreamVByte variant, samples per row): the svb16 stage of VBZ runs on the GPU, one stream per signal-table row."""
+        from . import pod5_io
+        return (16, pod5_io.SIGNAL_CHUNK) if os.environ.get("S2S_POD5_SIGNAL", "vbz") == "vbz" else None
+
+    def svb_records(self, read_ids, offsets, row_read, row_offsets, blob) -> list:
+        """dac_records() for reads whose samples arrive as svb16 streams, one per signal-table row (row i belongs to read
+        row_read[i]; rows past a read's end are empty).  The zstd stage follows in write_records()."""
+        from . import pod5_io
+        if self._stream_run_info is None:
+            self._stream_run_info = self.run_info()
+        rows_of = {}
+        for i in range(len(row_read)):
+            if row_offsets[i + 1] > row_offsets[i]:
+                rows_of.setdefault(int(row_read[i]), []).append(i)
+        recs = []
+        for r, rid in enumerate(read_ids):
+            idx = self._stream_idx
+            self._stream_idx += 1
+            n = int(offsets[r + 1] - offsets[r])
+            if n <= 0:
+                continue
+            rec = self._record(idx, rid, None, self._stream_run_info)
+            rec["num_samples"] = n
+            rec["svb_rows"] = [(blob[row_offsets[i]:row_offsets[i + 1]], min(pod5_io.SIGNAL_CHUNK, n - j * pod5_io.SIGNAL_CHUNK))
+                               for j, i in enumerate(rows_of.get(r, []))]
+            recs.append(rec)
+        return recs
+
+    def _zstd_rows(self, recs) -> None:
+        """svb_rows -> vbz_rows: every svb16 stream of the batch becomes one zstd frame, on the native worker threads."""
+        import ctypes as C
+        from ._lib import lib
+        rows = [row for r in recs for row in r.get("svb_rows", ())]
+        if not rows:
+            return
+        offs = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum([len(b) for b, _ in rows], out=offs[1:])
+        first = rows[0][0]
+        flat = np.concatenate([np.frombuffer(b, np.uint8) for b, _ in rows]) if len(rows) > 1 else np.frombuffer(first, np.uint8)
+        L = lib()
+        cap = int(L.s2s_blow5_pack_bound(int(offs[-1]), len(rows)))
+        out, out_offs = np.empty(cap, np.uint8), np.zeros(len(rows) + 1, np.int64)
+        got = L.s2s_compress_rows(flat.ctypes.data, offs.ctypes.data, len(rows), 2, 1, min(64, len(os.sched_getaffinity(0))),
+                                  out.ctypes.data, cap, out_offs.ctypes.data)
+        if got < 0:
+            raise RuntimeError(f"s2s_compress_rows failed ({got})")
+        i = 0
+        for r in recs:
+            if "svb_rows" in r:
+                k = len(r["svb_rows"])
+                r["vbz_rows"] = [(out[out_offs[i + j]:out_offs[i + j + 1]].tobytes(), r["svb_rows"][j][1]) for j in range(k)]
+                del r["svb_rows"]
+                i += k
+
     def write_records(self, recs) -> None:
+        self._zstd_rows(recs)
         if self._stream is None:
             from . import pod5_io
             logger.warning("POD5 output comes from seq2squiggle_amd's own container writer: record content and the VBZ codec "

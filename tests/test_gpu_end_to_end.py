@@ -66,11 +66,15 @@ def test_model_object_export_flow(tmp_path, mode, tag, profile_name):
     check_file(tmp_path / "o.blow5", exp, [n for _, n in reads])
 
 
-@pytest.mark.parametrize("ext", [".blow5", ".slow5", ".pod5"])
-def test_streaming_path_equals_predict_step_path(tmp_path, ext):
-    """run_streaming (GPU zero-strip + DAC, no per-chunk Python objects) writes the same file content as the
-    reference-shaped predict_step / export_and_clear_results / writer.save() flow, samplers on, fixed seed."""
+@pytest.mark.parametrize("ext", [".blow5", ".slow5", ".pod5", ".blow5+svb-zd"])
+def test_streaming_path_equals_predict_step_path(tmp_path, ext, monkeypatch):
+    """run_streaming (GPU zero-strip + DAC, no per-chunk Python objects; for .pod5 and svb-zd .blow5 also the StreamVByte
+    stage of the signal codec on the GPU and the record / row compression on native threads) writes the same file content as
+    the reference-shaped predict_step / export_and_clear_results / writer.save() flow, samplers on, fixed seed."""
     from seq2squiggle_amd.cli import set_config
+    if ext.endswith("+svb-zd"):
+        ext = ".blow5"
+        monkeypatch.setenv("S2S_BLOW5_SIGNAL", "svb-zd")
     outs = []
     rng = np.random.default_rng(1)
     fa = tmp_path / "reads.fa"
