@@ -84,9 +84,9 @@ def end_to_end(mode):
     fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
     out_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
-    def run(n_reads):
+    def run(n_reads, ext="blow5"):
         with tempfile.TemporaryDirectory(dir=out_dir) as td:
-            out = os.path.join(td, "o.blow5")
+            out = os.path.join(td, "o." + ext)
             set_seeds(42)
             t0 = time.perf_counter()
             m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
@@ -104,12 +104,17 @@ def end_to_end(mode):
     first, _, _ = run(1000)            # the first call also pays the process's one-time costs (pinned buffers, thread pools)
     el, chunks, size = run(1000)
     el3, chunks3, size3 = run(12500)
+    run(1000, "pod5")
+    elp, chunksp, sizep = run(1000, "pod5")
     return {"workload": "example lambda genome -n 1000 -r 5000 -> .blow5 (zlib records), seed 42", "seconds": el,
             "first_call_seconds": first, "reads_per_sec": 1000 / el, "chunks": chunks, "chunks_per_sec": chunks / el,
             "output_bytes": size, "output_dir": out_dir or tempfile.gettempdir(),
             "config3_share": {"workload": "example lambda genome -n 12500 -r 5000 -> .blow5: one GPU's share of configs[2]",
                               "seconds": el3, "reads_per_sec": 12500 / el3, "chunks": chunks3, "chunks_per_sec": chunks3 / el3,
                               "output_bytes": size3},
+            "pod5": {"workload": "configs[1]'s reads -> .pod5 (VBZ signal rows: svb16 on the GPU, zstd on host threads), the "
+                                 "container BASELINE configs[4] asks for", "seconds": elp, "reads_per_sec": 1000 / elp,
+                     "chunks": chunksp, "chunks_per_sec": chunksp / elp, "output_bytes": sizep},
             "includes": "engine creation, read sampling, chunking, kernels, export, D2H, compression, file write"}
 
 

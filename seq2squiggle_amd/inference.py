@@ -147,6 +147,7 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
     copy_stream = torch.cuda.Stream(dev)      # D2H of finished super-batches
     up_stream = torch.cuda.Stream(dev)        # H2D of the next one (its own stream: never queued behind a D2H that waits for kernels)
+    blob_stream = torch.cuda.Stream(dev)      # exact-size D2H of a finished batch's coded signal (not behind the NEXT batch's small copies)
 
     staging = _STAGING.setdefault(str(dev), (_Staging(dev), _Staging(dev)))   # super-batch i + 2 reuses i's buffer: i has been collected by then
     n_launched = 0
@@ -225,10 +226,11 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         if gpu_rows:
             rows_h, blob_d, row_read = payload
             row_offs = rows_h.numpy()
-            with torch.cuda.stream(copy_stream):          # the blob, now that its size is known (the kernels are long done)
+            with torch.cuda.stream(blob_stream):          # the blob, now that its size is known (its kernels are long done)
                 blob_h = torch.empty(int(row_offs[-1]), dtype=torch.uint8, pin_memory=True)
                 blob_h.copy_(blob_d[: int(row_offs[-1])], non_blocking=True)
-            copy_stream.synchronize()
+                blob_d.record_stream(blob_stream)
+            blob_stream.synchronize()
             recs = writer.svb_records(ids, offs, row_read, row_offs, blob_h.numpy())
         else:
             recs = writer.dac_records(ids, payload.numpy()[: int(offs[-1])], offs)

@@ -521,20 +521,27 @@ class POD5Writer:
             return
         offs = np.zeros(len(rows) + 1, np.int64)
         np.cumsum([len(b) for b, _ in rows], out=offs[1:])
-        first = rows[0][0]
-        flat = np.concatenate([np.frombuffer(b, np.uint8) for b, _ in rows]) if len(rows) > 1 else np.frombuffer(first, np.uint8)
+        # svb_records hands over consecutive slices of the one blob that came off the GPU: no copy then
+        first = rows[0][0].__array_interface__["data"][0]
+        if all(b.__array_interface__["data"][0] == first + int(offs[i]) for i, (b, _) in enumerate(rows)):
+            src, keep = C.c_void_p(first), rows
+        else:
+            keep = np.concatenate([np.frombuffer(b, np.uint8) for b, _ in rows])
+            src = C.c_void_p(keep.ctypes.data)
         L = lib()
         cap = int(L.s2s_blow5_pack_bound(int(offs[-1]), len(rows)))
         out, out_offs = np.empty(cap, np.uint8), np.zeros(len(rows) + 1, np.int64)
-        got = L.s2s_compress_rows(flat.ctypes.data, offs.ctypes.data, len(rows), 2, 1, min(64, len(os.sched_getaffinity(0))),
+        got = L.s2s_compress_rows(src, offs.ctypes.data, len(rows), 2, 1, min(64, len(os.sched_getaffinity(0))),
                                   out.ctypes.data, cap, out_offs.ctypes.data)
+        del keep
         if got < 0:
             raise RuntimeError(f"s2s_compress_rows failed ({got})")
+        view = memoryview(out)
         i = 0
         for r in recs:
             if "svb_rows" in r:
                 k = len(r["svb_rows"])
-                r["vbz_rows"] = [(out[out_offs[i + j]:out_offs[i + j + 1]].tobytes(), r["svb_rows"][j][1]) for j in range(k)]
+                r["vbz_rows"] = [(view[out_offs[i + j]:out_offs[i + j + 1]], r["svb_rows"][j][1]) for j in range(k)]
                 del r["svb_rows"]
                 i += k
 
