@@ -1021,6 +1021,9 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
         if ((e = hipMalloc(&h->ws_counts, (size_t)cap * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(export counts)");
         if ((e = hipMalloc(&h->ws_offs, (size_t)cap * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc(export offsets)");
         h->ws_export_cap = cap;
+        const int rows = 16384;        // s2s_svb_encode scratch: rows of a super-batch (POD5: ~6 per 10 kb read)
+        if ((e = hipMalloc(&h->ws_svb, (size_t)rows * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(svb rows)");
+        h->ws_svb_cap = rows;
     }
     const struct { const void* fn; int bytes; } dyn_lds[] = {
         {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), Fused<0>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), Fused<1>::LDS},
