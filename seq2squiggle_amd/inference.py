@@ -327,7 +327,7 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
                 return lo, hi
             reads, lens = sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of)
             first_chunk, first_read = picked["first"], picked["lo"]
-            logger.info(f"rank {rank}/{world}: {len(reads)} of {len(lens)} reads, first global chunk {first_chunk}")
+            logger.info(f"rank {rank}/{world}: reads {picked['lo']}.. of {len(lens)}, first global chunk {first_chunk}")
         else:
             reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len, lazy=world == 1)
             if world > 1:                  # read mode: every rank parses the same file, then keeps its contiguous share

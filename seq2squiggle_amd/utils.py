@@ -177,14 +177,14 @@ def locate(contig_ends, position):
     return i, position - (contig_ends[i - 1] if i else 0)
 
 
-def read_check(read, read_length, read_i, profile, min_read_len=30):
+def read_check(read, read_length, read_i, profile, min_read_len=30, may_have_n=True):
     """utils.py:381-400: DNA reads must have the full drawn length (end-of-contig rejection), be at least
-    min_read_len long and carry at most 10 % N."""
+    min_read_len long and carry at most 10 % N (may_have_n = False: the contig is known to hold none)."""
     if profile.startswith("dna") and len(read) != read_length:
         return False
     if len(read) < min_read_len:
         return False
-    if read.count("N") > 0.1 * read_length:
+    if may_have_n and read.count("N") > 0.1 * read_length:
         return False
     return True
 
@@ -235,6 +235,7 @@ def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr,
         return int(vals[read_i - lo])
 
     contig_ends = list(itertools.accumulate(genome_lens))
+    contig_has_n = ["N" in g_ for g_ in genome_seqs]      # one scan per contig instead of one per read
     is_dna = profile.startswith("dna")
 
     def attempt(read_i, retry):
@@ -250,9 +251,9 @@ def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr,
             length = int(draw_length(distr, r, seed + read_i * (max_retries + 1) + retry, total_len))
         read = genome[offset:offset + length]
         strand = random.choice("+-") if is_dna else "+"
-        if not read_check(read, length, read_i, profile, min_read_len):
+        if not read_check(read, length, read_i, profile, min_read_len, contig_has_n[where]):
             return None
-        return (fill_unknown_bases(read) if "N" in read else read), strand
+        return (fill_unknown_bases(read) if contig_has_n[where] and "N" in read else read), strand
 
     for read_i in range(num_seqs):
         for retry in range(max_retries):
@@ -296,7 +297,8 @@ def _check_sampling_args(n, r, c):
 def sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of):
     """One rank's share of the read set sample_reads_from_reference would draw: pass 1 replays the sampler for the read
     LENGTHS only, `shard_of(lengths)` -> (lo, hi) picks the rank's contiguous range, pass 2 replays it from the same
-    `random` state and builds the strings of that range.  -> (reads lo..hi-1 as (seq, uuid) pairs, all read lengths)."""
+    `random` state, builds the strings of that range only and stops behind it.  Pass 2 is lazy: the predict loop pulls the
+    rank's reads while it packs batches.  -> (iterator over reads lo..hi-1 as (seq, uuid) pairs, all read lengths)."""
     _check_sampling_args(n, r, c)
     total_len = sum(len(seq) for seq in genome_seqs)
     seq_num = n if n != -1 else round(c * total_len / r)
@@ -304,8 +306,15 @@ def sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, m
     lens = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(0, 0))
     lo, hi = shard_of(lens)
     random.setstate(state)
-    reads = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(lo, hi))
-    return [(rd, str(uuid4())) for rd in reads[lo:hi]], lens
+
+    def own_reads():
+        for i, rd in enumerate(sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
+                                             materialise=(lo, hi))):
+            if i >= hi:
+                return
+            if i >= lo:
+                yield rd, str(uuid4())
+    return own_reads(), lens
 
 
 def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta, seed, save=False, distr="expon",
