@@ -291,7 +291,6 @@ class BLOW5Writer:
         sig_offs = np.zeros(n + 1, np.int64)
         np.cumsum([s_.size for s_ in sigs], out=sig_offs[1:])
         # the records of a super-batch are consecutive slices of one packed array (run_streaming): no copy then
-        base = sigs[0].base if sigs[0].base is not None else sigs[0]
         first = sigs[0].__array_interface__["data"][0]
         contiguous = all(s_.__array_interface__["data"][0] == first + int(sig_offs[i]) for i, s_ in enumerate(sigs))
         sig = np.concatenate(sigs) if not contiguous else None
@@ -302,11 +301,9 @@ class BLOW5Writer:
         if self._out is None or self._out.size < cap:              # kept between batches: no fresh pages per call
             self._out = np.empty(cap + cap // 4, np.uint8)
         out = self._out
-        threads = self.threads
         got = L.s2s_blow5_pack(head.ctypes.data, head_offs.ctypes.data, tail.ctypes.data, tail_offs.ctypes.data, C.c_void_p(sig_ptr),
                                sig_offs.ctypes.data, n, self.RECORD_METHODS[self.record_compression], self.compress_level,
-                               threads, out.ctypes.data, cap)
-        del base
+                               self.threads, out.ctypes.data, cap)   # (`fields` keeps the sample arrays alive across the call)
         if got < 0:
             raise RuntimeError(f"s2s_blow5_pack failed ({got})")
         return memoryview(out)[:got]
