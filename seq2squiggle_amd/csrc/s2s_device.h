@@ -195,8 +195,9 @@ __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int lane,
 }
 
 // nn.LayerNorm(64, eps=1e-5) over the feature axis (registers + the 4 lane groups), in place; gm/bt: this lane's
-// slices of weight and bias.
-template <int NQ>
+// slices of weight and bias.  HW: 1/sqrt on the hardware transcendental (v_rsq_f32, 1 ulp) instead of the correctly rounded
+// sqrt + division sequences (about 25 instructions) -- the f16x3 blocks, whose operands carry 22 bits anyway.
+template <int NQ, bool HW = false>
 __device__ __forceinline__ void layer_norm64_r(f32x4 (&x)[NQ][4], const f32x4 (&gm)[4], const f32x4 (&bt)[4]) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -211,20 +212,21 @@ __device__ __forceinline__ void layer_norm64_r(f32x4 (&x)[NQ][4], const f32x4 (&
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float d = x[q][ft][r] - mean; v += d * d; }
-        const float rstd = 1.0f / sqrtf(sum_g(v) * (1.0f / 64.0f) + 1e-5f);
+        const float var = sum_g(v) * (1.0f / 64.0f) + 1e-5f;
+        const float rstd = HW ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[q][ft][r] = (x[q][ft][r] - mean) * rstd * gm[ft][r] + bt[ft][r];
     }
 }
-template <int NQ>
+template <int NQ, bool HW = false>
 __device__ __forceinline__ void layer_norm64(f32x4 (&x)[NQ][4], const float* __restrict__ gam,
                                              const float* __restrict__ bet, int g) {
     f32x4 gm[4], bt[4];
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) { gm[ft] = ldg4(gam + 16 * ft + 4 * g); bt[ft] = ldg4(bet + 16 * ft + 4 * g); }
-    layer_norm64_r<NQ>(x, gm, bt);
+    layer_norm64_r<NQ, HW>(x, gm, bt);
 }
 
 // Barrier between the phases of a block that exchange K/V through LDS.  SOLO: the block's sequence is one time tile owned

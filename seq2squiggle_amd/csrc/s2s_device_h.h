@@ -445,7 +445,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const f32x4 t = LO ? oH[q] + oL[q] : oH[q];
-                    const float inv = 1.0f / (LO ? lH[q][0] + lL[q][0] : lH[q][0]);
+                    const float inv = __builtin_amdgcn_rcpf(LO ? lH[q][0] + lL[q][0] : lH[q][0]);   // v_rcp_f32 (1 ulp), not the 10-instruction division
                     f32x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {            // O[d] = row d + row 8+d: the other half-wave's value
@@ -538,7 +538,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int hc = 0; hc < 4; ++hc)
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(wst + (8 * hc + wave) * 1024 + i * 256) = stage[4 * hc + i];
-        layer_norm64_r<NQ>(acc, gm, bt);                             // acc = x1
+        layer_norm64_r<NQ, true>(acc, gm, bt);                             // acc = x1
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -548,7 +548,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];              // W1 unit 0 (requested during the last P.V)
         if constexpr (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
         SB_GEMM();
-        layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);            // acc = x1
+        layer_norm64<NQ, true>(acc, W + L.ln1g, W + L.ln1b, g);            // acc = x1
     }
     if constexpr (!FFN_LDS) DIAG_STAMP(4);
     HL x1b[NQ][2];
@@ -619,7 +619,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         }
     }
     DIAG_STAMP(5);
-    layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+    layer_norm64<NQ, true>(X, W + L.ln2g, W + L.ln2b, g);
     DIAG_STAMP(6);
 }
 
@@ -714,7 +714,7 @@ __device__ __forceinline__ void enc_attention_h(const float* __restrict__ W, con
                     split2(e2, e3, one, h1, l1);
                     const h8 P1 = __builtin_bit_cast(h8, (uv4{h0, h1, h0, h1}));
                     const h8 P2 = __builtin_bit_cast(h8, (uv4{l0, l1, 0u, 0u}));
-                    inv[hh] = 1.0f / sum_g((e0 + e1) + (e2 + e3));   // (the halves above carry these to 22 bits)
+                    inv[hh] = __builtin_amdgcn_rcpf(sum_g((e0 + e1) + (e2 + e3)));   // (the halves above carry these to 22 bits)
                     O[hh] = MFMAH(Va, P1, (f32x4{0, 0, 0, 0}));       // rows: the pair's features 4g..4g+3, column: query c
                     O[hh] = MFMAH(Va, P2, O[hh]);
                 }
@@ -747,7 +747,7 @@ template <int NQ>
 __device__ __forceinline__ void enc_ffn_begin_h(const float* __restrict__ W, const LayerOff L, f32x4 (&acc)[NQ][4], f32x4 (&X)[NQ][4],
                                                 HL (&x1b)[NQ][2], const int lane, const float one) {
     const int g = lane >> 4;
-    layer_norm64<NQ>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
+    layer_norm64<NQ, true>(acc, W + L.ln1g, W + L.ln1b, g);                // acc = x1
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { x1b[q][0] = split8(acc[q][0], acc[q][1], one); x1b[q][1] = split8(acc[q][2], acc[q][3], one); }
 #pragma unroll

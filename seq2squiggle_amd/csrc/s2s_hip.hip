@@ -277,7 +277,7 @@ __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __r
         enc_ffn_begin_h<NQ>(W, L, acc, X, x1b, lane, one);
         enc_ffn_half_h<NQ>(W, L, wl + 16 * 1024, 0, x1b, X, lane, one);
         enc_ffn_half_h<NQ>(W, L, wl + 32 * 1024, 2, x1b, X, lane, one);
-        layer_norm64<NQ>(X, W + L.ln2g, W + L.ln2b, g);
+        layer_norm64<NQ, true>(X, W + L.ln2g, W + L.ln2b, g);
         DIAG_STAMP(3);
     }
     front_store<NQ>(io, dbg, X, lane, true);
