@@ -247,6 +247,31 @@ def test_native_record_packer_equals_the_python_framing(tmp_path, rec):
         assert unpack(w._pack_native(scattered)) == got
 
 
+@pytest.mark.parametrize("method", [1, 2])
+def test_native_row_compressor(method):
+    """s2s_compress_rows: every row a stream of its own (zlib container / zstd frame), empty rows and n = 0 included, output
+    bounds in out_offs, too small a buffer refused."""
+    import ctypes as C, zlib
+    from seq2squiggle_amd import codecs
+    from seq2squiggle_amd._lib import lib
+    L = lib()
+    rng = np.random.default_rng(9)
+    rows = [rng.integers(0, 7, n).astype(np.uint8).tobytes() for n in (0, 1, 5000, 0, 123457, 17)]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    flat = np.frombuffer(b"".join(rows) + b"\0", np.uint8)
+    cap = int(L.s2s_blow5_pack_bound(int(offs[-1]), len(rows)))
+    out, out_offs = np.zeros(cap, np.uint8), np.full(len(rows) + 1, -1, np.int64)
+    got = L.s2s_compress_rows(flat.ctypes.data, offs.ctypes.data, len(rows), method, 1, 5, out.ctypes.data, cap, out_offs.ctypes.data)
+    assert got == out_offs[-1] > 0 and out_offs[0] == 0 and np.all(np.diff(out_offs) > 0)
+    for i, r in enumerate(rows):
+        blob = out[out_offs[i]:out_offs[i + 1]].tobytes()
+        back = zlib.decompress(blob) if method == 1 else codecs.zstd_decompress(blob, len(r))
+        assert back == r
+    assert L.s2s_compress_rows(flat.ctypes.data, offs.ctypes.data, len(rows), method, 1, 5, out.ctypes.data, 100, out_offs.ctypes.data) < 0
+    assert L.s2s_compress_rows(None, None, 0, method, 1, 5, None, 0, out_offs.ctypes.data) == 0 and out_offs[0] == 0
+    assert L.s2s_compress_rows(flat.ctypes.data, offs.ctypes.data, len(rows), 7, 1, 5, out.ctypes.data, cap, out_offs.ctypes.data) < 0
+
+
 def test_onehot_to_bases_equals_chunker():
     from seq2squiggle_amd.model import onehot_to_bases
     lut = np.full(256, 255, np.uint8)
