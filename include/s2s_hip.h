@@ -188,11 +188,10 @@ int s2s_svb_encode(s2s_handle* h, void* stream, const int16_t* samples, const in
 int s2s_philox_u32(s2s_handle* h, void* stream, uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
                    uint32_t c3, int32_t n, uint32_t* out /* device [n][4] */);
 
-/* Average device time (ms) of the dominant (decoder) kernel over the launches since the last
+/* Device time (ms) of the predict kernel (s2s_fused_kernel: frontend + decoder in one launch) over the launches since the last
  * call, measured with HIP events on the launch stream when profiling is enabled. */
 int s2s_set_profiling(s2s_handle* h, int32_t enabled);
-int s2s_get_kernel_ms(s2s_handle* h, double* decoder_ms_total, int64_t* decoder_launches,
-                      int64_t* decoder_chunks);
+int s2s_get_kernel_ms(s2s_handle* h, double* kernel_ms_total, int64_t* launches, int64_t* chunks);
 
 /* ---- host-side helper (no GPU work, no handle): frames and compresses one batch of BLOW5 records on `threads` worker
  * threads -- what pyslow5's write_record_batch(threads = cpu_count) does for the reference (signal_io.py:167-171).
@@ -214,7 +213,7 @@ int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n_r
                           int32_t threads, uint8_t* out, int64_t capacity, int64_t* out_offs);
 
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): 48 per-phase wave-cycle sums since the
- * last call (0-15 decoder, 16-31 the encoder blocks of the frontend, 32-47 the frontend's own
+ * last call (0-15 decoder, 16-31 unused, 32-47 the frontend's own
  * phases; tools/diag_phases.py names them); S2S_ERR_ARG in a normal build. */
 int s2s_diag_read(s2s_handle* h, uint64_t* out48);
 

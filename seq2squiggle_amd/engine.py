@@ -206,7 +206,7 @@ class Engine:
         self._check(_lib.lib().s2s_set_profiling(self._h, int(enabled)), "s2s_set_profiling")
 
     def kernel_ms(self):
-        """-> (total decoder-kernel ms, launches, chunks) since the last call (HIP events on the launch stream)."""
+        """-> (total predict-kernel ms, launches, chunks) since the last call (HIP events on the launch stream)."""
         ms, nl, nc = C.c_double(), C.c_int64(), C.c_int64()
         self._check(_lib.lib().s2s_get_kernel_ms(self._h, C.byref(ms), C.byref(nl), C.byref(nc)), "s2s_get_kernel_ms")
         return ms.value, nl.value, nc.value
