@@ -415,13 +415,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int head = 2 * p + hh;
-#ifdef S2S_PRIO_ALT
-                // the two waves of a SIMD (w and w + 4) take turns at the higher issue priority, head by head, so that
-                // neither is the arbitration loser for the whole attention phase
-                if (WAVES == 8) {
-                    if (((head + (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                }
-#endif
                 h8 qb[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
@@ -493,9 +486,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             }
         }
     }
-#ifdef S2S_PRIO_ALT
-    if (WAVES == 8) __builtin_amdgcn_s_setprio(0);
-#endif
     if constexpr (!(S2S_FFN_LDS && WAVES == 8 && LO)) DIAG_STAMP(3);
 
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
