@@ -8,6 +8,9 @@
 typedef size_t (*blob_floats_fn)(const s2s_config*);
 typedef int (*create_fn)(const s2s_config*, const void*, size_t, int, s2s_handle**);
 typedef const char* (*last_error_fn)(const s2s_handle*);
+typedef int64_t (*pack_bound_fn)(int64_t, int32_t);
+typedef int64_t (*pack_fn)(const uint8_t*, const int64_t*, const uint8_t*, const int64_t*, const uint8_t*, const int64_t*, int32_t,
+                           int32_t, int32_t, int32_t, uint8_t*, int64_t);
 
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
@@ -35,6 +38,17 @@ int main(int argc, char** argv) {
     cfg.n_heads = 8;
     float dummy[4] = {0};
     if (create(&cfg, dummy, sizeof dummy, 0, &h) != S2S_ERR_BLOB) return 10;
+    /* the host-side record packer needs no GPU: two records, stored uncompressed, from plain C */
+    pack_bound_fn pack_bound = (pack_bound_fn)dlsym(lib, "s2s_blow5_pack_bound");
+    pack_fn pack = (pack_fn)dlsym(lib, "s2s_blow5_pack");
+    const uint8_t head[] = "AB", tail[] = "xyz", sig[] = {1, 2, 3, 4, 5, 6};
+    const int64_t head_offs[] = {0, 1, 2}, tail_offs[] = {0, 1, 3}, sig_offs[] = {0, 2, 6};
+    uint8_t out[4096];
+    if (pack_bound(12, 2) > (int64_t)sizeof out) return 11;
+    const int64_t got = pack(head, head_offs, tail, tail_offs, sig, sig_offs, 2, 0, 1, 3, out, sizeof out);
+    const uint8_t want[] = {4, 0, 0, 0, 0, 0, 0, 0, 'A', 1, 2, 'x', 7, 0, 0, 0, 0, 0, 0, 0, 'B', 3, 4, 5, 6, 'y', 'z'};
+    if (got != (int64_t)sizeof want || memcmp(out, want, sizeof want)) return 12;
+    if (pack(head, head_offs, tail, tail_offs, sig, sig_offs, 2, 0, 1, 3, out, 8) >= 0) return 13;   /* too small a buffer */
     printf("CABI_OK %zu\n", n);
     return 0;
 }
