@@ -33,6 +33,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define S2S_FFN_LDS 1           // decoder FFN weights staged once per workgroup in the dead K/V region (0: every wave streams them from L2)
 #endif
 #define S2S_PF_FLOATS (1024 + 16 + 16)   // one frontend -> decoder hand-off slot (s2s_hip.hip: S2S_SLOT_FLOATS)
+#define S2S_SV_FLOATS 960                // bq_nat, bk_nat, bq, bk, bv, bfc (64 each), b1 (256), b2, ln1g, ln1b, ln2g, ln2b (64 each)
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
 // Scheduling barriers pin the weight-unit / K,V-fragment loads in front of the MFMAs they are prefetched behind; the
 // -DS2S_NO_SB_* builds measure what they are worth (the one in the attention pass: 15 % of the kernel).
@@ -173,12 +174,12 @@ __device__ __forceinline__ void linear64_h(const float* __restrict__ wu, const f
     for (int mt = 0; mt < 4; ++mt) {
         f32x4 f[4], t[NQ];
         load_unit(f, wu + mt * 1024 + lane * 4);
+        const f32x4 b = ldg4(bias + 16 * mt + 4 * g);           // the bias: C operand of the tile's first MFMA
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
+        for (int q = 0; q < NQ; ++q) t[q] = b;
         mm_unit_h<NQ>(t, f, xb);
-        const f32x4 b = ldg4(bias + 16 * mt + 4 * g);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) y[q][mt] = t[q] + b;
+        for (int q = 0; q < NQ; ++q) y[q][mt] = t[q];
     }
 }
 
@@ -314,8 +315,19 @@ template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
                                             unsigned long long* diag_buf = nullptr, const float* __restrict__ pf_src = nullptr,
-                                            float* __restrict__ pf_dst = nullptr) {
+                                            float* __restrict__ pf_dst = nullptr, float* __restrict__ sv_lds = nullptr) {
     using G = AttnLdsH<NQ, WAVES, NKT>;
+    // SV: the layer's small vectors (biases, LayerNorm weights: S2S_SV_FLOATS contiguous floats from L.bq_nat, pack_layer) are
+    // copied into LDS at the block's entry -- one f32x4 per thread, loaded before the entry barrier, stored after it, visible
+    // from the K/V barrier on -- so that every later use is a ds_read instead of an L2 round trip in front of the MFMAs or
+    // the LayerNorm that needs it.  (bk / bv are needed before that barrier and stay global, one pair ahead.)
+    constexpr bool SV = (WAVES == 8);                 // (the decoder; a single-wave instantiation reads them from L2)
+    auto svp = [&](const int off) -> const float* {
+        if constexpr (SV) return sv_lds + (off - L.bq_nat); else return W + off;
+    };
+    const int sv_i = wave * 64 + lane;
+    f32x4 svv = f32x4{0, 0, 0, 0};
+    if (SV && sv_i < S2S_SV_FLOATS / 4) svv = ldg4(W + L.bq_nat + 4 * sv_i);
     constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
@@ -333,19 +345,23 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 
     if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // every wave is done reading the previous block's K/V
     DIAG_STAMP(0);
+    if (SV && sv_i < S2S_SV_FLOATS / 4) *reinterpret_cast<f32x4*>(sv_lds + 4 * sv_i) = svv;
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
+    f32x4 bk_n = ldg4(W + L.bk_nat + 4 * g);
+    float bv_n = W[L.bv + c];                                  // V comes out transposed: this lane's column is one feature
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
         if (S2S_ABL & 4096) { for (int i = 0; i < 4; ++i) fb[i] = fa[i]; } else load_unit_h<LO>(fb, ws);   // (4096: timing without this phase's loads)
         WS_ADVP(UF, 2048);                                   // Wv, pair p
-        const f32x4 bk = ldg4(W + L.bk_nat + 16 * p + 4 * g);
-        const float bv = W[L.bv + 16 * p + c];                 // V comes out transposed: this lane's column is one feature
+        const f32x4 bk = bk_n;
+        const float bv = bv_n;
+        bk_n = ldg4(W + L.bk_nat + 16 * (p < 3 ? p + 1 : 3) + 4 * g);    // the next pair's, behind this pair's MFMAs
+        bv_n = W[L.bv + 16 * (p < 3 ? p + 1 : 3) + c];
         SB_GEMM();
-        // bias is added after the GEMM: the inline-asm split below must read results of compiler-visible
-        // VALU instructions, never an MFMA accumulator directly (MFMA -> VALU read needs wait states)
+        // the biases are the accumulators' initial values (the C operand of each tile's first MFMA): no add afterwards
         f32x4 ak[NQ], av[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; }
+        for (int q = 0; q < NQ; ++q) { ak[q] = bk; av[q] = f32x4{bv, bv, bv, bv}; }
         mm_unit_h<NQ, LO>(ak, fa, xb);
         SB_GEMM();
         if (!(S2S_ABL & 4096) || p == 3) load_unit_h<LO>(fa, ws);
@@ -359,10 +375,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             const int T = qt0 + q;
             const int key = 16 * T + c;
             h4 hi, lo;
-            split4<LO>(ak[q] + bk, one, hi, lo);
+            split4<LO>(ak[q], one, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
-            split4<LO>(av[q] + bv, one, hi, lo);                      // 4 consecutive keys of one V^T row: one b64 store each
+            split4<LO>(av[q], one, hi, lo);                           // 4 consecutive keys of one V^T row: one b64 store each
             const int vcol = G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
             *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
@@ -372,7 +388,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     f32x4 acc[NQ][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 b = ldg4(W + L.bfc + 16 * mt + 4 * g);
+        const f32x4 b = ldg4(svp(L.bfc) + 16 * mt + 4 * g);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
@@ -392,11 +408,11 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             const int p = 2 * u + pp;
             // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
             if (pp == 0) { load_unit_h<LO>(fb, ws); WS_ADVP(UF, 8192); } else { load_unit_h<LO>(fa, ws); WS_ADVP(UF, 8192); }
-            const f32x4 bq = ldg4(W + L.bq_nat + 16 * p + 4 * g);
+            const f32x4 bq = ldg4(svp(L.bq_nat) + 16 * p + 4 * g);   // (pack_layer: Wq and bq of the f16 streams carry the log2(e)/sqrt(d_k) factor)
             SB_GEMM();
             f32x4 qa[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) qa[q] = f32x4{0, 0, 0, 0};
+            for (int q = 0; q < NQ; ++q) qa[q] = bq;
             if (pp == 0) mm_unit_h<NQ, LO>(qa, fa, xb); else mm_unit_h<NQ, LO>(qa, fb, xb);
             SB_GEMM();
             // Q^T rows live 4 per lane group; the S MFMA wants all 8 d of a head in every lane
@@ -404,7 +420,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 h4 hi, lo;
-                split4<LO>((qa[q] + bq) * c1, one, hi, lo);               // scores come out in log2 units
+                split4<LO>(qa[q], one, hi, lo);                           // scores come out in log2 units
                 *reinterpret_cast<h4*>(Ql + ((((g >> 1) * NQ + q) * 2 + 0) * 16 + c) * 8 + 4 * (g & 1)) = hi;   // [head of the pair][q][hi|lo][c][8 d]
                 *reinterpret_cast<h4*>(Ql + ((((g >> 1) * NQ + q) * 2 + 1) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
@@ -510,8 +526,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int i = 0; i < 4; ++i) stage[4 * hc + i] = ldg4(ws + (8 * hc + wave - 1) * 1024 + i * 256);   // (ws is already one unit into the FFN)
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
-            gm[ft] = ldg4(W + L.ln1g + 16 * ft + 4 * g); bt[ft] = ldg4(W + L.ln1b + 16 * ft + 4 * g);
-            b2v[ft] = ldg4(W + L.b2 + 16 * ft + 4 * g);
+            gm[ft] = ldg4(svp(L.ln1g) + 16 * ft + 4 * g); bt[ft] = ldg4(svp(L.ln1b) + 16 * ft + 4 * g);
+            b2v[ft] = ldg4(svp(L.b2) + 16 * ft + 4 * g);
         }
         // piggy-back (the decoder's last layer): PF_FLOATS floats from pf_src -> LDS at pf_dst, visible to every wave after
         // the second barrier below like the weights themselves
@@ -538,7 +554,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int i = 0; i < 4; ++i) ring[0][i] = fa[i];              // W1 unit 0 (requested during the last P.V)
         if constexpr (RD == 4) { load_unit_h<LO>(ring[1], ws); load_unit_h<LO>(ring[2], ws + UF); WS_ADVP(2 * UF, 16384); }
         SB_GEMM();
-        layer_norm64<NQ, true>(acc, W + L.ln1g, W + L.ln1b, g);            // acc = x1
+        layer_norm64<NQ, true>(acc, svp(L.ln1g), svp(L.ln1b), g);          // acc = x1
     }
     if constexpr (!FFN_LDS) DIAG_STAMP(4);
     HL x1b[NQ][2];
@@ -555,7 +571,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 b = ldg4(W + L.b2 + 16 * mt + 4 * g);
+            const f32x4 b = ldg4(svp(L.b2) + 16 * mt + 4 * g);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;  // X = bias + residual accumulator
         }
@@ -565,12 +581,12 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         f32x4 hid[NQ][4];
         f32x4 b1[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(W + L.b1 + 64 * hc + 16 * mt + 4 * g);
+        for (int mt = 0; mt < 4; ++mt) b1[mt] = ldg4(svp(L.b1) + 64 * hc + 16 * mt + 4 * g);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W1 units: rows 64hc + 16mt ..
             f32x4 t[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
+            for (int q = 0; q < NQ; ++q) t[q] = b1[mt];   // (the bias: C operand of the tile's first MFMA)
             if constexpr (FFN_LDS) {                  // unit 8hc + mt + RM, three ahead of its use (wraps past the end: harmless)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ring[(mt + RM) & RM][i] = ldg4(wl + ((8 * hc + mt + RM) & 31) * 1024 + i * 256);
@@ -584,7 +600,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r] + b1[mt][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
         }
         HL hb[NQ][2];
 #pragma unroll
@@ -609,7 +625,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         }
     }
     DIAG_STAMP(5);
-    layer_norm64<NQ, true>(X, W + L.ln2g, W + L.ln2b, g);
+    layer_norm64<NQ, true>(X, svp(L.ln2g), svp(L.ln2b), g);
     DIAG_STAMP(6);
 }
 
@@ -664,7 +680,7 @@ __device__ __forceinline__ void enc_attention_h(const float* __restrict__ W, con
             SB_GEMM();
             f32x4 ak[NQ], av[NQ], aq[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { ak[q] = f32x4{0, 0, 0, 0}; av[q] = f32x4{0, 0, 0, 0}; aq[q] = f32x4{0, 0, 0, 0}; }
+            for (int q = 0; q < NQ; ++q) { ak[q] = bk; av[q] = f32x4{bv, bv, bv, bv}; aq[q] = bq; }   // biases: the first MFMAs' C operands
             mm_unit_h<NQ>(ak, fk, xb);
             mm_unit_h_t<NQ>(av, fv, xb);
             mm_unit_h<NQ>(aq, fq, xb);
@@ -679,9 +695,9 @@ __device__ __forceinline__ void enc_attention_h(const float* __restrict__ W, con
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 h4 khi, klo, vhi, vlo, qhi, qlo;
-                split4(ak[q] + bk, one, khi, klo);
-                split4(av[q] + bv, one, vhi, vlo);
-                split4((aq[q] + bq) * c1, one, qhi, qlo);
+                split4(ak[q], one, khi, klo);
+                split4(av[q], one, vhi, vlo);
+                split4(aq[q], one, qhi, qlo);             // (Wq, bq carry the log2(e)/sqrt(d_k) factor: scores in log2 units)
                 const uv2 kh = __builtin_bit_cast(uv2, khi), kl = __builtin_bit_cast(uv2, klo);
                 const uv2 vh = __builtin_bit_cast(uv2, vhi), vl = __builtin_bit_cast(uv2, vlo);
                 const uv2 qh = __builtin_bit_cast(uv2, qhi), ql = __builtin_bit_cast(uv2, qlo);
@@ -768,7 +784,7 @@ __device__ __forceinline__ void enc_ffn_half_h(const float* __restrict__ W, cons
             const int un = 8 * h + mt;                // this unit's index inside wl; the next one is requested now
             f32x4 t[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) t[q] = f32x4{0, 0, 0, 0};
+            for (int q = 0; q < NQ; ++q) t[q] = b1[mt];
             load_unit_h<true>(ring[(un + 1) & 1], wl + (un + 1) * UF);
             SB_GEMM();
             mm_unit_h<NQ>(t, ring[un & 1], x1b);
@@ -776,7 +792,7 @@ __device__ __forceinline__ void enc_ffn_half_h(const float* __restrict__ W, cons
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r] + b1[mt][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
         }
         HL hb[NQ][2];
 #pragma unroll

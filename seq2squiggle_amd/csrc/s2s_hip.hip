@@ -361,10 +361,11 @@ __device__ __forceinline__ void dec_blocks(const ModelDev& M, const float* __res
     const int qt0 = DEC_NQ * wave;
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
+        float* const slot_lds = reinterpret_cast<float*>(lds_raw + DEC_LDS_H), *const sv_lds = slot_lds + S2S_SLOT_FLOATS;
         if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
-                                                                          l == M.dec_layers - 1 ? next_slot : nullptr,
-                                                                          reinterpret_cast<float*>(lds_raw + DEC_LDS_H));
-        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag);
+                                                                          l == M.dec_layers - 1 ? next_slot : nullptr, slot_lds, sv_lds);
+        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
+                                                                                      nullptr, slot_lds, sv_lds);
         else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, reinterpret_cast<float*>(lds_raw), qt0, lane, diag);
     }
 }
@@ -431,7 +432,7 @@ template <int MODE> struct Fused {
     static constexpr int FNQ = (FMODE == 1) ? 2 : 1;              // chunks per frontend wave
     static constexpr int GROUP = DEC_WAVES * FNQ;
     static constexpr bool PF = (MODE == 1);                       // next chunk's slot prefetched into LDS (dec_blocks)
-    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (PF ? S2S_SLOT_FLOATS * 4 : 0);
+    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS) * 4;   // + next slot, small vectors
     static_assert(LDS <= 160 * 1024, "LDS per workgroup");
     static_assert(FMODE == 1 || DEC_WAVES * FrontLdsF32::BYTES <= LDS, "the f32 frontend waves' K/V images share the decoder's LDS");
 };
@@ -846,7 +847,12 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     st.resize(st.size() + 1024, 0.0f);       // the block's last prefetch reads one unit past its stream
     L.stream = A.put(st.data(), st.size());
     // the same units for the split-f16 block: per (m-tile, k-block of 32) a hi and a lo fragment of
-    // 64 lanes x 8 halves; lane (g, i), element j: W[16mt + i][kbase + 16(j>>2) + 4g + (j&3)]
+    // 64 lanes x 8 halves; lane (g, i), element j: W[16mt + i][kbase + 16(j>>2) + 4g + (j&3)].
+    // Wq and bq go in pre-multiplied by log2(e)/sqrt(d_k): Q leaves its GEMM in the units the softmax wants (layers.py:32-33).
+    const float c1 = 1.4426950408889634f * 0.35355339059327373f;
+    std::vector<float> wq_s(wq, wq + 4096), bq_s(bq, bq + 64);
+    for (float& v : wq_s) v *= c1;
+    for (float& v : bq_s) v *= c1;
     std::vector<_Float16> sh;
     auto frag_h = [&](const float* Wm, int K, int mt, int kbase, bool lo) {
         for (int lane = 0; lane < 64; ++lane) {
@@ -863,8 +869,8 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     };
     for (int p_ = 0; p_ < 4; ++p_) { unit_h(wk, 64, p_, 0); unit_h(wv, 64, p_, 0); }
     for (int u = 0; u < 2; ++u) {
-        unit_h(wq, 64, 2 * u, 0);
-        unit_h(wq, 64, 2 * u + 1, 0);
+        unit_h(wq_s.data(), 64, 2 * u, 0);
+        unit_h(wq_s.data(), 64, 2 * u + 1, 0);
         for (int mt = 0; mt < 4; ++mt) { frag_h(wfc, 64, mt, 32 * u, false); frag_h(wfc, 64, mt, 32 * u, true); }
     }
     for (int hc = 0; hc < 4; ++hc) {
@@ -883,7 +889,7 @@ LayerOff pack_layer(Arena& A, const float*& p) {
         std::memcpy(rawf.data(), sf.data(), sf.size() * sizeof(_Float16));
         L.stream_f = A.put(rawf.data(), rawf.size());
     }
-    L.bq_nat = A.put(bq, 64);
+    L.bq_nat = A.put(bq_s.data(), 64);         // (f16 blocks only; the f32 block reads L.bq)
     L.bk_nat = A.put(bk, 64);
     L.bq = A.put_bias_perm(bq, 64);
     L.bk = A.put_bias_perm(bk, 64);
