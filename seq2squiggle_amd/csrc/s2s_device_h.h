@@ -384,6 +384,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
         }
     }
+    DIAG_STAMP(1);
+    if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // K/V of every wave visible (and the small vectors: svp() from here on)
+    DIAG_STAMP(2);
     // ---- fc accumulator starts as bias + residual (layers.py:85-86)
     f32x4 acc[NQ][4];
 #pragma unroll
@@ -392,9 +395,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
-    DIAG_STAMP(1);
-    if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // K/V of every wave visible
-    DIAG_STAMP(2);
 
     const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
     h8 ones;
