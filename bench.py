@@ -160,7 +160,9 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
     """Oracle (CPU port of the reference op sequence, torch fp32 'highest') on the host cores, plus a live parity
     check of the engine against it on the first 256 chunks of the sample (injected variates)."""
     from oracle import s2s_oracle as O
+    from seq2squiggle_amd.signal_io import cpu_share
     torch.set_float32_matmul_precision("highest")
+    torch.set_num_threads(cpu_share())      # the cores this container may actually keep busy (cgroup quota), not the host's count
     reads = make_reads(4, 99)
     codes = np.concatenate([O.encode_read(r, cfg["seq_kmer"]) for r in reads], 0)[:1024]
     p = O.PredictParams()
@@ -197,7 +199,7 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
               "dwell_indices_equal": bool(np.array_equal(got["dur"].cpu().numpy(), ref["dur"].numpy())),
               "zero_pattern_equal": bool(np.array_equal(y == 0, r == 0)), "tolerance_mae_pa": 1e-4}
     return {"value": done * 250 / el, "unit": "samples/s", "cores": torch.get_num_threads(), "parity": parity,
-            "host_logical_cpus": len(os.sched_getaffinity(0)), "kind": "port",
+            "host_logical_cpus": len(os.sched_getaffinity(0)), "cpu_quota": cpu_share(), "kind": "port",
             "reads_per_sec": done / CHUNKS_PER_READ / el, "value_matmul_precision_medium": done_m * 250 / el_m,
             "sample": f"{done} chunks (batches of 1024, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
 

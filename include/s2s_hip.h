@@ -198,7 +198,9 @@ int s2s_get_kernel_ms(s2s_handle* h, double* kernel_ms_total, int64_t* launches,
  * Record i's body is prefix[prefix_offs[i] : prefix_offs[i+1]] + signal[signal_offs[i] : signal_offs[i+1]] +
  * suffix[suffix_offs[i] : suffix_offs[i+1]] (the fields before and after raw_signal, built by the caller; the signal bytes
  * are little-endian int16 samples or an svb-zd blob); `out` receives, in record order, [u64 compressed size][body compressed
- * with `method`: 0 none, 1 zlib container (RFC 1950; written by libdeflate when that library loads, else zlib), 2 zstd] at
+ * with `method`: 0 none, 1 zlib container (RFC 1950; written by libdeflate when that library loads, else zlib), 2 zstd, 3 zlib
+ * container written by the library's own Huffman-only deflate encoder (dynamic blocks of literals, no match search; a record is
+ * coded in independent pieces of <= 128 KiB on several threads and is still ONE ordinary zlib stream; `level` is ignored)] at
  * `level`.  `capacity` must be at least s2s_blow5_pack_bound(total body bytes, n).  Returns the bytes written, or < 0. */
 int64_t s2s_blow5_pack_bound(int64_t body_bytes_total, int32_t n_records);
 int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const uint8_t* suffix, const int64_t* suffix_offs,

@@ -21,6 +21,9 @@ _LAYER = ("slf_attn.w_qs.weight", "slf_attn.w_qs.bias", "slf_attn.w_ks.weight", 
 _MLP = ("0.weight", "0.bias", "3.weight", "3.bias")
 
 
+_PARSED = {}              # (real path, mtime_ns, size, allow_pickle) -> (state_dict, config) of the last file read
+
+
 def load_checkpoint(path: str, allow_pickle: bool = None) -> Tuple[Dict[str, torch.Tensor], dict]:
     """-> (state_dict, config).  Only `state_dict` and `hyper_parameters["config"]` are required.
 
@@ -30,6 +33,11 @@ def load_checkpoint(path: str, allow_pickle: bool = None) -> Tuple[Dict[str, tor
     from the file."""
     if allow_pickle is None:
         allow_pickle = os.environ.get("S2S_ALLOW_PICKLE", "") == "1"
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_mtime_ns, st.st_size, bool(allow_pickle))
+    hit = _PARSED.get(key)
+    if hit is not None:                     # same file as last time (a service predicting again): skip the unpickling
+        return dict(hit[0]), dict(hit[1])
     try:
         ck = torch.load(path, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError as e:
@@ -42,7 +50,10 @@ def load_checkpoint(path: str, allow_pickle: bool = None) -> Tuple[Dict[str, tor
     cfg = (ck.get("hyper_parameters") or {}).get("config")
     if cfg is None:
         raise ValueError(f"{path}: checkpoint carries no hyper_parameters['config']")
-    return {k: v.detach().float().cpu() for k, v in ck["state_dict"].items()}, dict(cfg)
+    sd = {k: v.detach().float().cpu() for k, v in ck["state_dict"].items()}
+    _PARSED.clear()                         # one entry: the last checkpoint read
+    _PARSED[key] = (sd, dict(cfg))
+    return dict(sd), dict(cfg)
 
 
 def blob_names(cfg: dict):

@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <immintrin.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -713,6 +716,8 @@ struct s2s_handle {
     s2s_config cfg;
     int device = 0;
     ModelDev model;
+    char* slab = nullptr;             // ONE device allocation made by s2s_create: weights, hand-off slots, first scratch buffers
+    size_t slab_bytes = 0;
     float* d_arena = nullptr;
     size_t arena_floats = 0;
     int tile = 0;                     // chunks per launch pair
@@ -742,6 +747,12 @@ int fail(s2s_handle* h, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                 \
             return fail((h), S2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// Scratch that has outgrown its first home inside the handle's slab is an allocation of its own.
+void free_scratch(s2s_handle* h, void* p) {
+    const char* c = static_cast<const char*>(p);
+    if (p && !(h->slab && c >= h->slab && c < h->slab + h->slab_bytes)) (void)hipFree(p);
+}
 
 // Makes the handle's device current for the duration of a call and restores the caller's device afterwards.
 struct DeviceGuard {
@@ -808,6 +819,45 @@ struct Arena {
 
 const float* take(const float*& p, size_t n) { const float* q = p; p += n; return q; }
 
+// w = hi + lo with hi = f16(w), lo = f16(w - hi) (round to nearest even), for a whole matrix at once.  The host compiler turns a
+// plain _Float16 cast into a library call unless F16C code generation is on, and s2s_create converts half a million weights:
+// the F16C instance does eight per instruction and is picked at run time where the CPU has it.
+struct SplitF16 {
+    std::vector<_Float16> hi, lo;
+};
+void split_f16_generic(const float* w, size_t n, _Float16* hi, _Float16* lo) {
+    for (size_t i = 0; i < n; ++i) {
+        hi[i] = (_Float16)w[i];
+        lo[i] = (_Float16)(w[i] - (float)hi[i]);
+    }
+}
+__attribute__((target("avx,f16c"))) void split_f16_f16c(const float* w, size_t n, _Float16* hi, _Float16* lo) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m256 x = _mm256_loadu_ps(w + i);
+        const __m128i h = _mm256_cvtps_ph(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        const __m128i l = _mm256_cvtps_ph(_mm256_sub_ps(x, _mm256_cvtph_ps(h)), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(hi + i), h);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(lo + i), l);
+    }
+    for (; i < n; ++i) {
+        const __m128i h = _mm_cvtps_ph(_mm_set_ss(w[i]), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        const float back = _mm_cvtss_f32(_mm_cvtph_ps(h));
+        const __m128i l = _mm_cvtps_ph(_mm_set_ss(w[i] - back), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        const unsigned short hb = (unsigned short)_mm_extract_epi16(h, 0), lb = (unsigned short)_mm_extract_epi16(l, 0);
+        std::memcpy(hi + i, &hb, 2);
+        std::memcpy(lo + i, &lb, 2);
+    }
+}
+SplitF16 split_f16(const float* w, size_t n) {
+    SplitF16 s;
+    s.hi.resize(n);
+    s.lo.resize(n);
+    static const bool fast = __builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx");
+    (fast ? split_f16_f16c : split_f16_generic)(w, n, s.hi.data(), s.lo.data());
+    return s;
+}
+
 LayerOff pack_layer(Arena& A, const float*& p) {
     LayerOff L;
     const float* wq = take(p, 4096); const float* bq = take(p, 64);
@@ -823,6 +873,7 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     //   attention : per pair p: Wq rows of p, Wfc columns of p (m-tiles 0..3)
     //   FFN       : per 64-wide hidden slice hc: W1 m-tiles 4hc..4hc+3, then W2 m-tiles 0..3 x k-tiles 4hc..4hc+3
     std::vector<float> st;
+    st.reserve(4 * 4096 + 2 * 256 * 64 + 1024);
     auto frag = [&](const float* Wm, int K, int mt, int kt, bool perm) {
         for (int lane = 0; lane < 64; ++lane) {
             const int g = lane >> 4, i = lane & 15;
@@ -854,28 +905,28 @@ LayerOff pack_layer(Arena& A, const float*& p) {
     for (float& v : wq_s) v *= c1;
     for (float& v : bq_s) v *= c1;
     std::vector<_Float16> sh;
-    auto frag_h = [&](const float* Wm, int K, int mt, int kbase, bool lo) {
+    sh.reserve(2 * (4 * 4096 + 2 * 256 * 64) + 4 * 2048);
+    const SplitF16 hk = split_f16(wk, 4096), hv = split_f16(wv, 4096), hq = split_f16(wq_s.data(), 4096), hfc = split_f16(wfc, 4096);
+    const SplitF16 h1 = split_f16(w1, 256 * 64), h2 = split_f16(w2, 64 * 256);
+    auto frag_h = [&](const SplitF16& Wm, int K, int mt, int kbase, bool lo) {
+        const _Float16* src = lo ? Wm.lo.data() : Wm.hi.data();
         for (int lane = 0; lane < 64; ++lane) {
             const int g = lane >> 4, i = lane & 15;
-            for (int j = 0; j < 8; ++j) {
-                const float w = Wm[(size_t)(16 * mt + i) * K + kbase + 16 * (j >> 2) + 4 * g + (j & 3)];
-                const _Float16 hi = (_Float16)w;
-                sh.push_back(lo ? (_Float16)(w - (float)hi) : hi);
-            }
+            for (int j = 0; j < 8; ++j) sh.push_back(src[(size_t)(16 * mt + i) * K + kbase + 16 * (j >> 2) + 4 * g + (j & 3)]);
         }
     };
-    auto unit_h = [&](const float* Wm, int K, int mt, int kbase) {      // [kb0 hi][kb0 lo][kb1 hi][kb1 lo]
+    auto unit_h = [&](const SplitF16& Wm, int K, int mt, int kbase) {      // [kb0 hi][kb0 lo][kb1 hi][kb1 lo]
         for (int kb = 0; kb < 2; ++kb) { frag_h(Wm, K, mt, kbase + 32 * kb, false); frag_h(Wm, K, mt, kbase + 32 * kb, true); }
     };
-    for (int p_ = 0; p_ < 4; ++p_) { unit_h(wk, 64, p_, 0); unit_h(wv, 64, p_, 0); }
+    for (int p_ = 0; p_ < 4; ++p_) { unit_h(hk, 64, p_, 0); unit_h(hv, 64, p_, 0); }
     for (int u = 0; u < 2; ++u) {
-        unit_h(wq_s.data(), 64, 2 * u, 0);
-        unit_h(wq_s.data(), 64, 2 * u + 1, 0);
-        for (int mt = 0; mt < 4; ++mt) { frag_h(wfc, 64, mt, 32 * u, false); frag_h(wfc, 64, mt, 32 * u, true); }
+        unit_h(hq, 64, 2 * u, 0);
+        unit_h(hq, 64, 2 * u + 1, 0);
+        for (int mt = 0; mt < 4; ++mt) { frag_h(hfc, 64, mt, 32 * u, false); frag_h(hfc, 64, mt, 32 * u, true); }
     }
     for (int hc = 0; hc < 4; ++hc) {
-        for (int mt = 0; mt < 4; ++mt) unit_h(w1, 64, 4 * hc + mt, 0);
-        for (int mt = 0; mt < 4; ++mt) unit_h(w2, 256, mt, 64 * hc);
+        for (int mt = 0; mt < 4; ++mt) unit_h(h1, 64, 4 * hc + mt, 0);
+        for (int mt = 0; mt < 4; ++mt) unit_h(h2, 256, mt, 64 * hc);
     }
     sh.resize(sh.size() + 4 * 2048, (_Float16)0.0f);   // the FFN ring runs three units past the end of the stream
     {
@@ -904,18 +955,18 @@ LayerOff pack_layer(Arena& A, const float*& p) {
 
 // a 64x64 Linear as 4 f16 units (one per m-tile): [kb0 hi][kb0 lo][kb1 hi][kb1 lo], same fragment order as pack_layer
 int pack_linear64_h(Arena& A, const float* Wm) {
+    const SplitF16 hw = split_f16(Wm, 4096);
     std::vector<_Float16> sh;
+    sh.reserve(2 * 4096);
     for (int mt = 0; mt < 4; ++mt)
         for (int kb = 0; kb < 2; ++kb)
-            for (int lo = 0; lo < 2; ++lo)
+            for (int lo = 0; lo < 2; ++lo) {
+                const _Float16* src = lo ? hw.lo.data() : hw.hi.data();
                 for (int lane = 0; lane < 64; ++lane) {
                     const int g = lane >> 4, i = lane & 15;
-                    for (int j = 0; j < 8; ++j) {
-                        const float w = Wm[(size_t)(16 * mt + i) * 64 + 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3)];
-                        const _Float16 hi = (_Float16)w;
-                        sh.push_back(lo ? (_Float16)(w - (float)hi) : hi);
-                    }
+                    for (int j = 0; j < 8; ++j) sh.push_back(src[(size_t)(16 * mt + i) * 64 + 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3)]);
                 }
+            }
     std::vector<float> raw(sh.size() / 2);
     std::memcpy(raw.data(), sh.data(), sh.size() * sizeof(_Float16));
     return A.put(raw.data(), raw.size());
@@ -965,15 +1016,28 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if (device < 0 || device >= ndev) return fail(nullptr, S2S_ERR_ARG, "no such HIP device");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(nullptr, S2S_ERR_HIP, "hipSetDevice failed");
-    hipDeviceProp_t prop;
-    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(nullptr, S2S_ERR_ARG, std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only");
+    std::string arch;
+    int n_cu = 0;
+    {   // hipGetDeviceProperties is a millisecond-class call: asked once per device and process
+        static std::mutex mu;
+        static std::map<int, std::pair<std::string, int>> seen;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = seen.find(device);
+        if (it == seen.end()) {
+            hipDeviceProp_t prop;
+            HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+            it = seen.emplace(device, std::make_pair(std::string(prop.gcnArchName), prop.multiProcessorCount)).first;
+        }
+        arch = it->second.first;
+        n_cu = it->second.second;
+    }
+    if (arch.compare(0, 6, "gfx950") != 0)
+        return fail(nullptr, S2S_ERR_ARG, "device is " + arch + ", this library is gfx950 only");
 
     s2s_handle* h = new s2s_handle();
     h->cfg = *cfg;
     h->device = device;
-    h->n_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->n_wg = n_cu > 0 ? n_cu : 256;
     const int k = cfg->seq_kmer;
     Arena A;
     ModelDev& M = h->model;
@@ -1013,24 +1077,30 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
         return S2S_ERR_HIP;
     };
     hipError_t e;
-    if ((e = hipMalloc(&h->d_arena, h->arena_floats * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(arena)");
-    if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(e, "hipMemcpy(arena)");
     // chunks per launch: the kernel needs no per-chunk workspace, so a launch is as long as 32-bit chunk indices allow
     // comfortably (every launch ends in a tail of up to one chunk time per workgroup)
     h->tile = 1 << 20;
-    if ((e = hipMalloc(&h->handoff, (size_t)h->n_wg * S2S_MAX_GROUP * S2S_SLOT_FLOATS * sizeof(float))) != hipSuccess)
-        return bail(e, "hipMalloc(handoff)");
-    {   // export scratch for the streaming path's usual super-batch, so that its first s2s_export_reads does not have to
-        // drain the stream in order to grow it
-        const int cap = 2 * 32768 + 1;
-        if ((e = hipMalloc(&h->ws_counts, (size_t)cap * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(export counts)");
-        if ((e = hipMalloc(&h->ws_offs, (size_t)cap * sizeof(long long))) != hipSuccess) return bail(e, "hipMalloc(export offsets)");
+    {   // one allocation (each hipMalloc is a driver round trip): weights | hand-off slots | export scratch for the streaming
+        // path's usual super-batch, so that its first s2s_export_reads does not have to drain the stream in order to grow it |
+        // s2s_svb_encode scratch (rows of a super-batch; POD5: ~6 per 10 kb read)
+        const int cap = 2 * 32768 + 1, rows = 16384;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_hand = up(h->arena_floats * sizeof(float));
+        const size_t o_counts = o_hand + up((size_t)h->n_wg * S2S_MAX_GROUP * S2S_SLOT_FLOATS * sizeof(float));
+        const size_t o_offs = o_counts + up((size_t)cap * sizeof(int));
+        const size_t o_svb = o_offs + up((size_t)cap * sizeof(long long));
+        h->slab_bytes = o_svb + up((size_t)rows * sizeof(int));
+        if ((e = hipMalloc(&h->slab, h->slab_bytes)) != hipSuccess) return bail(e, "hipMalloc(handle)");
+        h->d_arena = reinterpret_cast<float*>(h->slab);
+        h->handoff = reinterpret_cast<float*>(h->slab + o_hand);
+        h->ws_counts = reinterpret_cast<int*>(h->slab + o_counts);
+        h->ws_offs = reinterpret_cast<long long*>(h->slab + o_offs);
+        h->ws_svb = reinterpret_cast<int*>(h->slab + o_svb);
         h->ws_export_cap = cap;
-        const int rows = 16384;        // s2s_svb_encode scratch: rows of a super-batch (POD5: ~6 per 10 kb read)
-        if ((e = hipMalloc(&h->ws_svb, (size_t)rows * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(svb rows)");
         h->ws_svb_cap = rows;
     }
+    if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(arena)");
     const struct { const void* fn; int bytes; } dyn_lds[] = {
         {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), Fused<0>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), Fused<1>::LDS},
         {reinterpret_cast<const void*>(s2s_fused_kernel<3, false>), Fused<3>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<0, true>), Fused<0>::LDS},
@@ -1050,11 +1120,10 @@ void s2s_destroy(s2s_handle* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     for (auto& ev : h->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    if (h->d_arena) (void)hipFree(h->d_arena);
-    if (h->handoff) (void)hipFree(h->handoff);
-    if (h->ws_counts) (void)hipFree(h->ws_counts);
-    if (h->ws_offs) (void)hipFree(h->ws_offs);
-    if (h->ws_svb) (void)hipFree(h->ws_svb);
+    free_scratch(h, h->ws_counts);
+    free_scratch(h, h->ws_offs);
+    free_scratch(h, h->ws_svb);
+    if (h->slab) (void)hipFree(h->slab);
     if (h->d_diag) (void)hipFree(h->d_diag);
     delete h;
 }
@@ -1141,8 +1210,8 @@ int s2s_export_reads(s2s_handle* h, void* stream_, const float* signal, int32_t 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (B + 1 > h->ws_export_cap) {          // grows outside of the steady state only
         HIP_TRY(h, hipStreamSynchronize(stream));
-        if (h->ws_counts) (void)hipFree(h->ws_counts);
-        if (h->ws_offs) (void)hipFree(h->ws_offs);
+        free_scratch(h, h->ws_counts);
+        free_scratch(h, h->ws_offs);
         h->ws_counts = nullptr; h->ws_offs = nullptr; h->ws_export_cap = 0;
         const int cap = B + 1 + B / 4;
         HIP_TRY(h, hipMalloc(&h->ws_counts, (size_t)cap * sizeof(int)));
@@ -1173,7 +1242,7 @@ int s2s_svb_encode(s2s_handle* h, void* stream_, const int16_t* samples, const i
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (N + 1 > h->ws_svb_cap) {             // grows outside of the steady state only
         HIP_TRY(h, hipStreamSynchronize(stream));
-        if (h->ws_svb) (void)hipFree(h->ws_svb);
+        free_scratch(h, h->ws_svb);
         h->ws_svb = nullptr; h->ws_svb_cap = 0;
         const int cap = N + 1 + N / 4;
         HIP_TRY(h, hipMalloc(&h->ws_svb, (size_t)cap * sizeof(int)));

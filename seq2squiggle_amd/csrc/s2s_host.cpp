@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -120,14 +121,186 @@ Pool* g_pool = nullptr;
 std::vector<std::vector<uint8_t>> g_scratch;   // per worker: the uncompressed body of the record it is on (kept between calls:
                                                // fresh pages every batch cost more than the compression of a small one)
 
+// ---- Huffman-only deflate (RFC 1951, dynamic blocks, literals only): the encoder of method 3.
+// A nanopore signal is noise on top of a level: LZ77 finds next to nothing in it (libdeflate level 1: 0.69-0.77 of the raw size,
+// Huffman coding of the bytes alone: 0.71-0.78), but the match search is what a deflate encoder spends its time in.  One piece =
+// one dynamic block with its own code + an empty stored block that pads to a byte boundary (and carries the final bit of the
+// last piece), so pieces are encoded independently and laid back to back.
+
+// Code lengths (<= max_len, a complete code) for freq[0..n): symbols with freq 0 get length 0; at least two symbols get a code.
+void huff_lengths(const uint32_t* freq_in, int n, int max_len, uint8_t* len_out) {
+    uint32_t freq[288];
+    int order[288], used = 0;
+    for (int i = 0; i < n; ++i) { freq[i] = freq_in[i]; len_out[i] = 0; }
+    for (int i = 0; i < n && used < 2; ++i) used += freq[i] != 0;
+    for (int i = 0; used < 2; ++i)                       // a decoder wants a complete code: give a second symbol a leaf
+        if (!freq[i]) { freq[i] = 1; ++used; }
+    used = 0;
+    for (int i = 0; i < n; ++i)
+        if (freq[i]) order[used++] = i;
+    std::sort(order, order + used, [&](int a, int b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
+    // two-queue Huffman: leaves in ascending order, internal nodes are created in ascending order as well
+    uint64_t w[576];
+    int parent[576];
+    for (int i = 0; i < used; ++i) w[i] = freq[order[i]];
+    int leaf = 0, inner = used, made = used;
+    auto take = [&]() { return (leaf < used && (inner >= made || w[leaf] <= w[inner])) ? leaf++ : inner++; };
+    while (made < 2 * used - 1) {
+        const int a = take(), b = take();
+        w[made] = w[a] + w[b];
+        parent[a] = parent[b] = made;
+        ++made;
+    }
+    int count[64] = {0};
+    for (int i = 0; i < used; ++i) {
+        int d = 0;
+        for (int v = i; v != made - 1; v = parent[v]) ++d;
+        ++count[d < 63 ? d : 63];
+    }
+    // enforce max_len: everything deeper moves up to max_len, then lengths are traded until the Kraft sum is exactly one
+    for (int d = max_len + 1; d < 64; ++d) { count[max_len] += count[d]; count[d] = 0; }
+    uint64_t total = 0;
+    for (int d = 1; d <= max_len; ++d) total += (uint64_t)count[d] << (max_len - d);
+    while (total > (1ull << max_len)) {
+        --count[max_len];
+        for (int d = max_len - 1; d > 0; --d)
+            if (count[d]) { --count[d]; count[d + 1] += 2; break; }
+        --total;
+    }
+    int at = 0;                                          // rarest symbols take the longest codes
+    for (int d = max_len; d >= 1; --d)
+        for (int c = 0; c < count[d]; ++c) len_out[order[at++]] = (uint8_t)d;
+}
+
+// canonical codes of the lengths, bit-reversed (deflate writes Huffman codes starting from their most significant bit)
+void huff_codes(const uint8_t* len, int n, uint16_t* code) {
+    int bl_count[16] = {0}, next[16];
+    for (int i = 0; i < n; ++i) ++bl_count[len[i]];
+    bl_count[0] = 0;
+    int c = 0;
+    for (int b = 1; b < 16; ++b) { c = (c + bl_count[b - 1]) << 1; next[b] = c; }
+    for (int i = 0; i < n; ++i) {
+        if (!len[i]) { code[i] = 0; continue; }
+        unsigned v = (unsigned)next[len[i]]++, r = 0;
+        for (int b = 0; b < len[i]; ++b) { r = (r << 1) | (v & 1); v >>= 1; }
+        code[i] = (uint16_t)r;
+    }
+}
+
+struct BitOut {
+    uint8_t* p;
+    uint64_t acc = 0;
+    int n = 0;
+    explicit BitOut(uint8_t* dst) : p(dst) {}
+    inline void put(uint32_t v, int bits) {              // bits <= 30; the buffer holds < 32 bits on entry
+        acc |= (uint64_t)v << n;
+        n += bits;
+        if (n >= 32) { std::memcpy(p, &acc, 4); p += 4; acc >>= 32; n -= 32; }      // (little-endian host)
+    }
+    uint8_t* finish() {                                  // pad to a byte boundary
+        while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
+        n = 0; acc = 0;
+        return p;
+    }
+};
+
+struct Segs {                                            // bytes [lo, hi) of the concatenation of up to three buffers
+    const uint8_t* p[3];
+    int64_t n[3];
+    template <class F> void each(int64_t lo, int64_t hi, F&& f) const {
+        int64_t base = 0;
+        for (int s = 0; s < 3; ++s) {
+            const int64_t a = lo > base ? lo : base, b = hi < base + n[s] ? hi : base + n[s];
+            if (b > a) f(p[s] + (a - base), b - a);
+            base += n[s];
+        }
+    }
+};
+
+// One piece -> dst (room >= len + len / 128 + 512): [dynamic block | stored blocks when those are smaller][empty stored block,
+// final bit = last].  Returns the bytes written; *adler = Adler-32 of the piece's bytes.
+int64_t huff_deflate_piece(const Segs& in, int64_t lo, int64_t hi, bool last, uint8_t* dst, uint32_t* adler) {
+    uint32_t hist[4][256];
+    std::memset(hist, 0, sizeof hist);
+    uint32_t ad = 1;
+    in.each(lo, hi, [&](const uint8_t* s, int64_t m) {
+        ad = (uint32_t)adler32(ad, s, (uInt)m);
+        int64_t i = 0;
+        for (; i + 4 <= m; i += 4) { ++hist[0][s[i]]; ++hist[1][s[i + 1]]; ++hist[2][s[i + 2]]; ++hist[3][s[i + 3]]; }
+        for (; i < m; ++i) ++hist[0][s[i]];
+    });
+    *adler = ad;
+    uint32_t freq[257];
+    for (int i = 0; i < 256; ++i) freq[i] = hist[0][i] + hist[1][i] + hist[2][i] + hist[3][i];
+    freq[256] = 1;                                       // end of block
+    uint8_t len[259];
+    huff_lengths(freq, 257, 15, len);
+    len[257] = len[258] = 1;                             // two distance codes of one bit, never used (what zlib sends as well)
+    uint32_t clfreq[19] = {0};
+    for (int i = 0; i < 259; ++i) ++clfreq[len[i]];
+    uint8_t cllen[19];
+    huff_lengths(clfreq, 16, 7, cllen);
+    cllen[16] = cllen[17] = cllen[18] = 0;               // the run-length symbols are not used: 259 lengths cost ~130 bytes
+    uint16_t code[257], clcode[19];
+    huff_codes(len, 257, code);
+    huff_codes(cllen, 19, clcode);
+    int64_t bits = 3 + 5 + 5 + 4 + 19 * 3;
+    for (int i = 0; i < 259; ++i) bits += cllen[len[i]];
+    for (int i = 0; i < 257; ++i) bits += (int64_t)freq[i] * len[i];
+    const int64_t n = hi - lo;
+    uint8_t* p = dst;
+    if ((bits + 7) / 8 >= n + 5 * ((n + 65534) / 65535)) {
+        // incompressible: stored blocks (byte-aligned by construction)
+        int64_t at = lo;
+        while (at < hi) {
+            const int64_t m = hi - at < 65535 ? hi - at : 65535;
+            *p++ = 0;
+            *p++ = (uint8_t)m; *p++ = (uint8_t)(m >> 8); *p++ = (uint8_t)~m; *p++ = (uint8_t)(~m >> 8);
+            in.each(at, at + m, [&](const uint8_t* s, int64_t k) { std::memcpy(p, s, k); p += k; });
+            at += m;
+        }
+    } else {
+        BitOut out(p);
+        out.put(0, 1);                                   // not the final block: the empty stored block below carries that bit
+        out.put(2, 2);                                   // dynamic Huffman codes
+        out.put(0, 5);                                   // HLIT: 257 literal/length codes
+        out.put(1, 5);                                   // HDIST: 2 distance codes
+        out.put(15, 4);                                  // HCLEN: all 19 code length codes
+        static const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (int i = 0; i < 19; ++i) out.put(cllen[cl_order[i]], 3);
+        for (int i = 0; i < 259; ++i) out.put(clcode[len[i]], cllen[len[i]]);
+        uint32_t tab[256];                               // code | length << 16
+        for (int i = 0; i < 256; ++i) tab[i] = code[i] | (uint32_t)len[i] << 16;
+        in.each(lo, hi, [&](const uint8_t* s, int64_t m) {
+            int64_t i = 0;
+            for (; i + 2 <= m; i += 2) {                 // two codes (<= 15 bits each) per buffer check
+                const uint32_t t = tab[s[i]], u = tab[s[i + 1]];
+                const int lt = (int)(t >> 16);
+                out.put((t & 0xFFFF) | (u & 0xFFFF) << lt, lt + (int)(u >> 16));
+            }
+            for (; i < m; ++i) { const uint32_t t = tab[s[i]]; out.put(t & 0xFFFF, (int)(t >> 16)); }
+        });
+        out.put(code[256], len[256]);
+        out.put(last ? 1 : 0, 1);                        // the empty stored block: final bit, type 00, pad, LEN 0, NLEN ~0
+        out.put(0, 2);
+        p = out.finish();
+        *p++ = 0; *p++ = 0; *p++ = 0xFF; *p++ = 0xFF;
+        return p - dst;
+    }
+    *p++ = last ? 1 : 0;                                 // after stored blocks the stream is byte-aligned already
+    *p++ = 0; *p++ = 0; *p++ = 0xFF; *p++ = 0xFF;
+    return p - dst;
+}
+
 }  // namespace
 
 extern "C" {
 
 int64_t s2s_blow5_pack_bound(int64_t body_bytes_total, int32_t n_records) {
     if (body_bytes_total < 0 || n_records < 0) return S2S_ERR_ARG;
-    // per record: u64 size + the worst case of the three codecs (zstd's bound is the largest: n + n/256 + 64)
-    return body_bytes_total + body_bytes_total / 128 + (int64_t)n_records * (8 + 1024);
+    // per record: u64 size + the worst case of the three codecs (zstd's bound is the largest: n + n/256 + 64); a long zlib
+    // record's pieces each end in a flush marker
+    return body_bytes_total + body_bytes_total / 64 + (int64_t)n_records * (8 + 1024) + 4096;
 }
 
 int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const uint8_t* suffix, const int64_t* suffix_offs,
@@ -135,33 +308,59 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
                        int32_t threads, uint8_t* out, int64_t capacity) {
     if (n < 0 || threads < 1 || (n > 0 && (!prefix || !prefix_offs || !suffix || !suffix_offs || !signal || !signal_offs || !out)))
         return S2S_ERR_ARG;
-    if (method < 0 || method > 2) return S2S_ERR_ARG;
+    if (method < 0 || method > 3) return S2S_ERR_ARG;
     if (method == 2 && !zstd().ok) return S2S_ERR_ARG;
     if (n == 0) return 0;
     std::lock_guard<std::mutex> guard(g_pool_mutex);
     if (!g_pool || g_pool->size() < threads) { delete g_pool; g_pool = new Pool(threads); }   // grows, never shrinks
     const int workers = g_pool->size();
+    const int zlevel = level < 1 ? 1 : (level > 9 ? 9 : level);
 
-    // slot i of `out`: room for record i's worst case, so that workers never wait for each other; compacted afterwards
-    std::vector<int64_t> slot(n + 1), size(n);
-    slot[0] = 0;
+    // One task per record -- except that a batch is only done when its longest record is: with method 3 a record is deflated
+    // as independent pieces of at most PIECE bytes (huff_deflate_piece); header + pieces + Adler-32 of the whole body are one
+    // ordinary zlib stream (RFC 1950).
+    constexpr int64_t PIECE = 128 << 10;
+    struct Task { int rec; int64_t lo, hi; bool piece, last; int64_t slot, room, size; uint32_t adler; };
+    std::vector<Task> tasks;
+    std::vector<int> first_task(n + 1);
+    int64_t need = 0;
     for (int i = 0; i < n; ++i) {
         const int64_t body = (prefix_offs[i + 1] - prefix_offs[i]) + (signal_offs[i + 1] - signal_offs[i]) + (suffix_offs[i + 1] - suffix_offs[i]);
-        slot[i + 1] = slot[i] + 8 + body + body / 128 + 1024;
+        first_task[i] = (int)tasks.size();
+        if (method == 3) {
+            const int64_t k = body > 0 ? (body + PIECE - 1) / PIECE : 1, len = body > 0 ? (body + k - 1) / k : 1;
+            for (int64_t lo = 0; lo < body || lo == 0; lo += len) {
+                const int64_t hi = lo + len < body ? lo + len : body;
+                const int64_t room = (hi - lo) + (hi - lo) / 128 + 512;
+                tasks.push_back({i, lo, hi, true, hi == body, need, room, 0, 0});
+                need += room;
+            }
+        } else {
+            const int64_t room = body + body / 128 + 1024;
+            tasks.push_back({i, 0, body, false, true, need, room, 0, 0});
+            need += room;
+        }
     }
-    if (slot[n] > capacity) return S2S_ERR_ARG;
+    first_task[n] = (int)tasks.size();
+    static std::vector<uint8_t> staged;            // compressed pieces before they are laid back to back (kept between calls)
+    if ((int64_t)staged.size() < need) staged.resize(need + need / 4);
     std::atomic<int> failed{0};
     if ((int)g_scratch.size() < workers) g_scratch.resize(workers);
     std::vector<std::vector<uint8_t>>& scratch = g_scratch;
     std::vector<void*> defl(workers, nullptr);
     const bool use_deflate = method == 1 && deflate().ok;
-    g_pool->run(n, [&](int i, int w) {
+    g_pool->run((int)tasks.size(), [&](int t, int w) {
+        Task& T = tasks[t];
+        const int i = T.rec;
         const int64_t np = prefix_offs[i + 1] - prefix_offs[i], ns = signal_offs[i + 1] - signal_offs[i], nx = suffix_offs[i + 1] - suffix_offs[i];
         const int64_t body = np + ns + nx;
-        uint8_t* dst = out + slot[i] + 8;
-        const int64_t room = slot[i + 1] - slot[i] - 8;
+        uint8_t* dst = staged.data() + T.slot;
         int64_t written = -1;
-        if (method == 0) {
+        if (T.piece) {
+            const Segs in = {{prefix + prefix_offs[i], signal + signal_offs[i], suffix + suffix_offs[i]}, {np, ns, nx}};
+            written = huff_deflate_piece(in, T.lo, T.hi, T.last, dst, &T.adler);
+            if (written > T.room) written = -1;
+        } else if (method == 0) {
             std::memcpy(dst, prefix + prefix_offs[i], np);
             std::memcpy(dst + np, signal + signal_offs[i], ns);
             std::memcpy(dst + np + ns, suffix + suffix_offs[i], nx);
@@ -173,32 +372,51 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
             std::memcpy(b.data() + np, signal + signal_offs[i], ns);
             std::memcpy(b.data() + np + ns, suffix + suffix_offs[i], nx);
             if (use_deflate) {
-                if (!defl[w]) defl[w] = deflate().alloc(level < 1 ? 1 : level);
-                const size_t r = defl[w] ? deflate().zlib_compress(defl[w], b.data(), body, dst, room) : 0;
+                if (!defl[w]) defl[w] = deflate().alloc(zlevel);
+                const size_t r = defl[w] ? deflate().zlib_compress(defl[w], b.data(), body, dst, T.room) : 0;
                 if (r) written = (int64_t)r;
             } else if (method == 1) {
-                uLongf dl = (uLongf)room;
+                uLongf dl = (uLongf)T.room;
                 if (compress2(dst, &dl, b.data(), (uLong)body, level) == Z_OK) written = (int64_t)dl;
             } else {
-                const size_t r = zstd().compress(dst, room, b.data(), body, level);
+                const size_t r = zstd().compress(dst, T.room, b.data(), body, level);
                 if (!zstd().is_error(r)) written = (int64_t)r;
             }
         }
         if (written < 0) { failed = 1; written = 0; }
-        size[i] = written;
-        const uint64_t sz = (uint64_t)written;
-        std::memcpy(out + slot[i], &sz, 8);                     // (little-endian host)
+        T.size = written;
     });
     for (void* d : defl)
         if (d) deflate().free_(d);
     if (failed) return S2S_ERR_HIP;
-    int64_t pos = 0;
-    for (int i = 0; i < n; ++i) {                               // close the gaps, in record order
-        const int64_t len = 8 + size[i];
-        if (pos != slot[i]) std::memmove(out + pos, out + slot[i], len);
-        pos += len;
+
+    // where every record lands in `out`, then the copies (again on the workers: 10+ MB per batch)
+    std::vector<int64_t> at(n + 1);
+    at[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t len = 0;
+        for (int t = first_task[i]; t < first_task[i + 1]; ++t) len += tasks[t].size;
+        if (tasks[first_task[i]].piece) len += 2 + 4;
+        at[i + 1] = at[i] + 8 + len;
     }
-    return pos;
+    if (at[n] > capacity) return S2S_ERR_ARG;
+    g_pool->run(n, [&](int i, int) {
+        uint8_t* dst = out + at[i];
+        const uint64_t sz = (uint64_t)(at[i + 1] - at[i] - 8);
+        std::memcpy(dst, &sz, 8);                               // (little-endian host)
+        dst += 8;
+        const bool split = tasks[first_task[i]].piece;
+        uint32_t ad = 1;
+        if (split) { *dst++ = 0x78; *dst++ = 0x01; }             // CMF/FLG: deflate, 32 K window, fastest, check bits
+        for (int t = first_task[i]; t < first_task[i + 1]; ++t) {
+            const Task& T = tasks[t];
+            std::memcpy(dst, staged.data() + T.slot, T.size);
+            dst += T.size;
+            if (split) ad = t == first_task[i] ? T.adler : (uint32_t)adler32_combine(ad, T.adler, (z_off_t)(T.hi - T.lo));
+        }
+        if (split) { dst[0] = (uint8_t)(ad >> 24); dst[1] = (uint8_t)(ad >> 16); dst[2] = (uint8_t)(ad >> 8); dst[3] = (uint8_t)ad; }
+    });
+    return at[n];
 }
 
 int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n, int32_t method, int32_t level, int32_t threads,

@@ -107,6 +107,7 @@ class _Staging:
 
 
 _STAGING = {}             # device -> the two pinned staging buffers, kept for the life of the process
+_STREAMS = {}             # device -> (download, upload, blob) copy streams, kept for the life of the process
 _IO = None
 _TRACE = None             # tools/e2e_timeline.py points this at a list to receive run_streaming's event times
 
@@ -120,6 +121,21 @@ def _io_executor():
         from concurrent.futures import ThreadPoolExecutor
         _IO = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-writer")
     return _IO
+
+
+def _copy_streams(dev):
+    """The three copy streams of run_streaming.  Made once per device and process and touched once here: a HIP stream gets its
+    hardware queue at its first submission, which costs milliseconds -- inference_run pays that on its loader thread."""
+    key = str(dev)
+    if key not in _STREAMS:
+        streams = tuple(torch.cuda.Stream(dev) for _ in range(3))
+        src = torch.zeros(64, dtype=torch.uint8, pin_memory=True)
+        for st in streams:
+            with torch.cuda.stream(st):
+                src.to(dev, non_blocking=True)
+            st.synchronize()
+        _STREAMS[key] = streams
+    return _STREAMS[key]
 
 
 def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
@@ -145,9 +161,9 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     io = _io_executor()
     pending = None            # the writer job of the previous super-batch
     inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
-    copy_stream = torch.cuda.Stream(dev)      # D2H of finished super-batches
-    up_stream = torch.cuda.Stream(dev)        # H2D of the next one (its own stream: never queued behind a D2H that waits for kernels)
-    blob_stream = torch.cuda.Stream(dev)      # exact-size D2H of a finished batch's coded signal (not behind the NEXT batch's small copies)
+    # copy_stream: D2H of finished super-batches; up_stream: H2D of the next one (its own stream: never queued behind a D2H that
+    # waits for kernels); blob_stream: exact-size D2H of a finished batch's coded signal (not behind the NEXT batch's small copies)
+    copy_stream, up_stream, blob_stream = _copy_streams(dev)
 
     staging = _STAGING.setdefault(str(dev), (_Staging(dev), _Staging(dev)))   # super-batch i + 2 reuses i's buffer: i has been collected by then
     n_launched = 0
@@ -173,14 +189,17 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         # H2D from pinned staging on the copy stream: a pageable copy on the compute stream would hold this thread until
         # the previous super-batch's kernels have drained
         ins = staging[n_launched % 2].upload(arrays, up_stream)
+        mark("uploaded")
         out = model.engine.predict_packed(ins[0], ins[1], ins[2], model._params(), first_global_chunk=model.chunks_done)
         model.chunks_done += B
         total += B
         n_launched += 1
+        mark("predict queued")
         ex = model.engine.export_reads(out["signal"], ins[3], profile_dict["digitisation"], profile_dict["range"],
                                        profile_dict["offset_mean"], rna=rna, want_pa=False, want_dac=True)
         names = [n for _, n in group]
         main = torch.cuda.current_stream(dev)
+        mark("export queued")
         if gpu_rows:
             # the signal leaves the GPU StreamVByte-coded (~1.1-1.3 bytes per sample): the small tables first, the blob in
             # collect() once its size is known
@@ -247,6 +266,15 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
 
     try:
         group, n = [], 0
+        # The first super-batches are short (1/8, 1/4, 1/2 of max_chunks): the GPU starts as soon as a few reads exist, and the
+        # host, which prepares a chunk faster than the GPU predicts one, is ahead from then on.  The last ones shrink again when
+        # the iterable says how many reads are left (operator.length_hint): what remains after the GPU's last kernel is the
+        # D2H + compression + write of the final super-batch only.
+        import operator
+        floor = max(max_chunks // 8, 1)
+        ramp = want = floor
+        seen_reads = seen_chunks = 0
+        reads = iter(reads)
         mark("first read wanted")
         for seq, name in reads:
             c = _n_chunks(len(seq), k)
@@ -255,12 +283,18 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
                 continue
             group.append((seq, name))
             n += c
-            if n >= max_chunks:
+            seen_reads += 1
+            seen_chunks += c
+            if n >= want:
                 job = launch(group)
                 if inflight is not None:
                     collect(inflight)
                 inflight = job
                 group, n = [], 0
+                ramp = want = min(2 * ramp, max_chunks)
+                left = operator.length_hint(reads, 0) * seen_chunks // seen_reads      # chunks still to come; 0: not known
+                if 0 < left < 2 * want:
+                    want = max(left // 2, floor)
         if group:
             job = launch(group)
             if inflight is not None:
@@ -309,8 +343,14 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     # on a helper thread while this one parses the FASTA and samples the reads
     from concurrent.futures import ThreadPoolExecutor
     loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-load")
+
+    def load(**kw):
+        m = seq2squiggle.load_from_checkpoint(**kw)
+        if streaming:
+            _copy_streams(m.device)
+        return m
     loading = loader.submit(
-        seq2squiggle.load_from_checkpoint, checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean,
+        load, checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean,
         dwell_std=dwell_std, noise_std=noise_std, noise_sampling=noise_sampling, duration_sampling=duration_sampling,
         export_every_n_samples=export_every_n_samples, min_noise=min_noise, min_duration=min_duration, device=local_rank,
         mode=mode, seed=seed)
@@ -337,6 +377,9 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
                 first_read = lo
                 logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
     finally:
+        if _TRACE is not None:
+            import time
+            _TRACE.append(("reads ready", time.perf_counter()))
         loader.shutdown(wait=True)
 
     if first_read:
@@ -346,6 +389,9 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     check_model(load_model, config)
 
     n_chunks = 0
+    if _TRACE is not None:
+        import time
+        _TRACE.append(("model ready", time.perf_counter()))
     if streaming and hasattr(writer, "dac_records"):
         n_chunks = run_streaming(load_model, reads, writer, profile_dict, profile, trace=_TRACE)
     else:

@@ -81,6 +81,27 @@ def _skip_record_draws(n_reads: int) -> None:
         np.random.normal(size=2 * (n_reads % 65536))
 
 
+def cpu_share() -> int:
+    """Worker threads this process may keep busy: the cores it is allowed on, capped by the container's CPU quota (cgroup
+    cpu.max -- more runnable threads than the quota buys get the whole group throttled for the rest of the scheduler period,
+    a stall of tens of milliseconds), divided between the ranks of a multi-process run on this node."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                          # cgroup v2: "<quota> <period>" | "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                quota, period = int(f.read()), int(g.read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(128, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+
+
 class BLOW5Writer:
     """Writes `.slow5` (ASCII) or `.blow5` (binary) by the file extension."""
 
@@ -111,7 +132,10 @@ class BLOW5Writer:
         self.n_written = 0
         self.binary = self.filename.endswith(".blow5")
         self.compress_level = 1               # zlib / zstd level of BLOW5 records; any level is a valid stream
-        self.threads = min(64, len(os.sched_getaffinity(0)))    # compression threads (the reference: cpu_count)
+        # zlib records: "huffman" = the library's own Huffman-only deflate (a noisy signal has no LZ77 matches worth the search:
+        # within 3 % of libdeflate level 1's size at a fifth of its CPU time, long records in parallel pieces); "lz" = libdeflate
+        self.deflate = "huffman"
+        self.threads = cpu_share()            # compression threads (the reference: cpu_count)
         self._out = None                      # packed records of the batch being written
 
     def start_at(self, read_index: int) -> None:
@@ -301,8 +325,11 @@ class BLOW5Writer:
         if self._out is None or self._out.size < cap:              # kept between batches: no fresh pages per call
             self._out = np.empty(cap + cap // 4, np.uint8)
         out = self._out
+        method = self.RECORD_METHODS[self.record_compression]
+        if self.record_compression == "zlib" and self.deflate == "huffman":
+            method = 3
         got = L.s2s_blow5_pack(head.ctypes.data, head_offs.ctypes.data, tail.ctypes.data, tail_offs.ctypes.data, C.c_void_p(sig_ptr),
-                               sig_offs.ctypes.data, n, self.RECORD_METHODS[self.record_compression], self.compress_level,
+                               sig_offs.ctypes.data, n, method, self.compress_level,
                                self.threads, out.ctypes.data, cap)   # (`fields` keeps the sample arrays alive across the call)
         if got < 0:
             raise RuntimeError(f"s2s_blow5_pack failed ({got})")
@@ -528,7 +555,7 @@ class POD5Writer:
         L = lib()
         cap = int(L.s2s_blow5_pack_bound(int(offs[-1]), len(rows)))
         out, out_offs = np.empty(cap, np.uint8), np.zeros(len(rows) + 1, np.int64)
-        got = L.s2s_compress_rows(src, offs.ctypes.data, len(rows), 2, 1, min(64, len(os.sched_getaffinity(0))),
+        got = L.s2s_compress_rows(src, offs.ctypes.data, len(rows), 2, 1, cpu_share(),
                                   out.ctypes.data, cap, out_offs.ctypes.data)
         del keep
         if got < 0:

@@ -271,8 +271,31 @@ def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr,
             logger.debug(f"Failed to sample a valid read after {max_retries} retries for read {read_i}. Skipping this read.")
 
 
-def yield_reads(reads):
-    return ((read, str(uuid4())) for read in reads)
+class CountedReads:
+    """An iterator over (sequence, read_id) pairs that knows how many are still to come (`operator.length_hint`): the predict
+    loop shortens its last super-batches with it."""
+
+    def __init__(self, pairs, count: int):
+        self._pairs = iter(pairs)
+        self._left = int(count)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = next(self._pairs)
+        self._left -= 1
+        return item
+
+    def __length_hint__(self):
+        return max(self._left, 0)
+
+
+def yield_reads(reads, count: int = None):
+    pairs = ((read, str(uuid4())) for read in reads)
+    if count is None and hasattr(reads, "__len__"):
+        count = len(reads)
+    return pairs if count is None else CountedReads(pairs, count)
 
 
 def export_fasta(read_l, fasta):
@@ -329,7 +352,8 @@ def sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, fasta
         logger.warning(f"Average reference sequence length ({avg_genome_len:.2f}) is smaller than the desired average "
                        f"read length ({r}). Reads longer than their reference sequence are skipped; consider a smaller -r.")
     if lazy and not save:
-        return (yield_reads(sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len)),
+        return (yield_reads(sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len),
+                            count=seq_num),
                 round(seq_num * r / config["max_dna_len"]))
     read_list = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len)
     total_l = sum(round(len(read) / config["max_dna_len"]) for read in read_list)
@@ -367,7 +391,7 @@ def get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read
         rng = random.Random(seed)
         sampled = [rng.choice(all_reads) for _ in range(n)]
         effective = sum(round(len(seq) / config["max_dna_len"]) for seq, _ in sampled)
-        return ((seq, str(uuid4())) for seq, _ in sampled), effective
+        return CountedReads(((seq, str(uuid4())) for seq, _ in sampled), len(sampled)), effective
     genome_seqs, genome_lens = preprocess_genome(fasta)
     reads_fasta, total_l = sample_reads_from_reference(genome_seqs, genome_lens, n, r, c, config, str(fasta), seed, save,
                                                        distr, profile, min_read_len, lazy=lazy)

@@ -216,7 +216,8 @@ def test_blow5_compression_methods(tmp_path, rec, sig):
 def test_native_record_packer_equals_the_python_framing(tmp_path, rec):
     """s2s_blow5_pack (host threads inside libs2s_hip.so) against _blow5_record, record by record after decompression:
     ragged sizes incl. a one-sample read, more threads than records and fewer, signals that are and are not slices of one
-    packed array, and a second call on the same (persistent) thread pool."""
+    packed array, a second call on the same (persistent) thread pool, and records long enough (> 160 KiB) to be deflated in
+    pieces -- those must still be single ordinary zlib streams (zlib.decompress takes them whole)."""
     import struct, zlib
     from seq2squiggle_amd import codecs
     rng = np.random.default_rng(5)
@@ -231,11 +232,13 @@ def test_native_record_packer_equals_the_python_framing(tmp_path, rec):
                        codecs.zstd_decompress(body, codecs.zstd_frame_content_size(body)) if rec == "zstd" else body)
             pos += 8 + n
         return out
-    for n_reads, threads in ((1, 4), (7, 2), (150, 64), (150, 3)):
+    for n_reads, threads in ((1, 4), (7, 2), (150, 64), (150, 3), (6, 8)):
         w = signal_io.BLOW5Writer(str(tmp_path / "p.blow5"), prof, False, "dna-r9-min", False, record_compression=rec)
         w.threads = threads
         lens = rng.integers(1, 40000, n_reads)
         lens[0] = 1
+        if n_reads == 6:
+            lens[1:] = (81900, 81920, 200000, 32768 * 7, 400001)        # bodies around and far beyond the split threshold
         offs = np.concatenate([[0], np.cumsum(lens)])
         dac = np.cumsum(rng.integers(-40, 41, int(offs[-1]))).astype(np.int16)
         np.random.seed(3)
@@ -245,6 +248,39 @@ def test_native_record_packer_equals_the_python_framing(tmp_path, rec):
         assert got == unpack(b"".join(want))
         scattered = [dict(r, signal=r["signal"].copy()) for r in recs]      # not slices of one array any more
         assert unpack(w._pack_native(scattered)) == got
+        if rec == "zlib":
+            w.deflate = "lz"                                                # libdeflate / zlib instead of the Huffman-only encoder
+            assert unpack(w._pack_native(recs)) == got
+
+
+def test_huffman_only_deflate_streams(tmp_path):
+    """The library's own deflate encoder (s2s_blow5_pack method 3) on inputs that reach every branch: incompressible bytes (stored
+    blocks), one repeated value, a geometric histogram (code lengths beyond 15 bits before limiting), tiny and multi-piece
+    records.  zlib.decompress must return the body and the stream must be smaller than stored + 1 % whenever it can be."""
+    import struct, zlib
+    rng = np.random.default_rng(11)
+    prof = U.get_profile("dna-r10-prom")
+    w = signal_io.BLOW5Writer(str(tmp_path / "h.blow5"), prof, False, "dna-r10-prom", False)
+    assert w.deflate == "huffman"
+    geo = np.minimum(rng.geometric(0.5, 300000), 40).astype(np.int16)        # p(v) ~ 2^-v: a 40-deep Huffman tree
+    sigs = [rng.integers(-32768, 32767, 100000).astype(np.int16), np.full(70001, 513, np.int16), geo,
+            np.array([7], np.int16), (600 + rng.normal(0, 30, 500000)).astype(np.int16), np.zeros(2, np.int16)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in sigs])])
+    np.random.seed(1)
+    recs = w.dac_records([f"r{i}" for i in range(len(sigs))], np.concatenate(sigs), offs)
+    buf = bytes(w._pack_native(recs))
+    pos = 0
+    for r, sig in zip(recs, sigs):
+        n = struct.unpack_from("<Q", buf, pos)[0]
+        body = zlib.decompress(buf[pos + 8: pos + 8 + n])
+        head, s_, tail = w._record_fields(r)
+        assert body == head + s_.tobytes() + tail
+        assert n <= len(body) * 1.01 + 64
+        pos += 8 + n
+    assert pos == len(buf)
+    assert struct.unpack_from("<Q", buf, 0)[0] > 200000                      # random int16: stored
+    second = 8 + struct.unpack_from("<Q", buf, 0)[0]
+    assert struct.unpack_from("<Q", buf, second)[0] < 70001 * 2 / 5          # two byte values: 1.5 bits per byte
 
 
 @pytest.mark.parametrize("method", [1, 2])
