@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
     pack_fn pack = (pack_fn)dlsym(lib, "s2s_blow5_pack");
     const uint8_t head[] = "AB", tail[] = "xyz", sig[] = {1, 2, 3, 4, 5, 6};
     const int64_t head_offs[] = {0, 1, 2}, tail_offs[] = {0, 1, 3}, sig_offs[] = {0, 2, 6};
-    uint8_t out[4096];
+    uint8_t out[8192];
     if (pack_bound(12, 2) > (int64_t)sizeof out) return 11;
     const int64_t got = pack(head, head_offs, tail, tail_offs, sig, sig_offs, 2, 0, 1, 3, out, sizeof out);
     const uint8_t want[] = {4, 0, 0, 0, 0, 0, 0, 0, 'A', 1, 2, 'x', 7, 0, 0, 0, 0, 0, 0, 0, 'B', 3, 4, 5, 6, 'y', 'z'};
