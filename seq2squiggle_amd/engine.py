@@ -153,9 +153,11 @@ class Engine:
     # ------------------------------------------------------------------ export
     def export_reads(self, signal: torch.Tensor, read_first: torch.Tensor, digitisation: float = 0.0,
                      signal_range: float = 1.0, offset_mean: float = 0.0, rna: bool = False, want_pa: bool = True,
-                     want_dac: bool = False):
+                     want_dac: bool = False, out_offsets: torch.Tensor = None, out_dac: torch.Tensor = None):
         """Per-read zero-strip (model.py:284-286) and optional int16 conversion (signal_io.py:134-141) on
-        the GPU.  signal [B,250]; read_first int32 [R+1] -> dict(offsets int64 [R+1], pa, dac)."""
+        the GPU.  signal [B,250]; read_first int32 [R+1] -> dict(offsets int64 [R+1], pa, dac).  out_offsets / out_dac: write
+        there instead of into fresh tensors (int64 [R+1] / int16 [>= B*250], e.g. two views of one buffer that then leaves the
+        device as a single copy)."""
         B, R = int(signal.shape[0]), int(read_first.shape[0]) - 1
         if signal.dtype != torch.float32 or not signal.is_contiguous() or signal.shape[1] != T_DEC:
             raise ValueError("signal must be contiguous float32 [B,250]")
@@ -163,10 +165,15 @@ class Engine:
             raise ValueError("read_first must be contiguous int32 [R+1]")
         if signal.device != self.device or read_first.device != self.device:
             raise ValueError(f"signal and read_first must live on {self.device}")
-        offs = torch.empty(R + 1, dtype=torch.int64, device=self.device)
         cap = B * T_DEC
+        for name, t, dt, n in (("out_offsets", out_offsets, torch.int64, R + 1), ("out_dac", out_dac, torch.int16, cap)):
+            if t is not None and (t.dtype != dt or t.dim() != 1 or not t.is_contiguous() or t.device != self.device or t.numel() < n):
+                raise ValueError(f"{name} must be a contiguous 1-D {dt} tensor of at least {n} elements on {self.device}")
+        offs = out_offsets[:R + 1] if out_offsets is not None else torch.empty(R + 1, dtype=torch.int64, device=self.device)
         pa = torch.empty(cap, dtype=torch.float32, device=self.device) if want_pa else None
-        dac = torch.empty(cap, dtype=torch.int16, device=self.device) if want_dac else None
+        dac = None
+        if want_dac or out_dac is not None:
+            dac = out_dac[:cap] if out_dac is not None else torch.empty(cap, dtype=torch.int16, device=self.device)
         with torch.cuda.device(self.device):
             rc = _lib.lib().s2s_export_reads(self._h, self._stream(), _ptr(signal), B, _ptr(read_first), R, _ptr(offs),
                                              _ptr(pa), _ptr(dac), cap, float(digitisation), float(signal_range),
@@ -174,10 +181,19 @@ class Engine:
         self._check(rc, "s2s_export_reads")
         return {"offsets": offs, "pa": pa, "dac": dac}
 
+    @staticmethod
+    def svb_capacity(total_samples_bound: int, n_rows: int, variant: int) -> int:
+        """Bytes s2s_svb_encode may write for n_rows rows holding at most total_samples_bound samples together."""
+        if variant == 32:
+            return 3 * total_samples_bound + 5 * n_rows
+        return 2 * total_samples_bound + total_samples_bound // 8 + n_rows
+
     def svb_encode(self, dac: torch.Tensor, read_offsets: torch.Tensor, row_read: torch.Tensor, row_index: torch.Tensor,
-                   row_samples: int, variant: int, total_samples_bound: int):
+                   row_samples: int, variant: int, total_samples_bound: int, out: torch.Tensor = None,
+                   out_offsets: torch.Tensor = None):
         """StreamVByte blobs of the rows (see s2s_svb_encode in include/s2s_hip.h) -> dict(out uint8 [capacity],
-        offsets int64 [N+1]) on the device.  total_samples_bound: an upper bound of the samples the rows hold together."""
+        offsets int64 [N+1]) on the device.  total_samples_bound: an upper bound of the samples the rows hold together.
+        out / out_offsets: write there (uint8 [>= svb_capacity(...)] / int64 [N+1]) instead of into fresh tensors."""
         N = int(row_read.shape[0])
         for name, t, dt in (("dac", dac, torch.int16), ("read_offsets", read_offsets, torch.int64),
                             ("row_read", row_read, torch.int32), ("row_index", row_index, torch.int32)):
@@ -185,9 +201,12 @@ class Engine:
                 raise ValueError(f"{name} must be a contiguous 1-D {dt} tensor on {self.device}")
         if row_index.shape[0] != N or variant not in (16, 32):
             raise ValueError("row_read / row_index differ in length, or variant is not 16 | 32")
-        cap = (3 * total_samples_bound + 5 * N) if variant == 32 else (2 * total_samples_bound + total_samples_bound // 8 + N)
-        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=self.device)
-        offs = torch.empty(N + 1, dtype=torch.int64, device=self.device)
+        cap = self.svb_capacity(total_samples_bound, N, variant)
+        for name, t, dt, n in (("out", out, torch.uint8, cap), ("out_offsets", out_offsets, torch.int64, N + 1)):
+            if t is not None and (t.dtype != dt or t.dim() != 1 or not t.is_contiguous() or t.device != self.device or t.numel() < n):
+                raise ValueError(f"{name} must be a contiguous 1-D {dt} tensor of at least {n} elements on {self.device}")
+        out = out if out is not None else torch.empty(max(cap, 1), dtype=torch.uint8, device=self.device)
+        offs = out_offsets[:N + 1] if out_offsets is not None else torch.empty(N + 1, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             rc = _lib.lib().s2s_svb_encode(self._h, self._stream(), _ptr(dac), _ptr(read_offsets), _ptr(row_read),
                                            _ptr(row_index), N, int(row_samples), int(variant), _ptr(out), cap, _ptr(offs))

@@ -107,7 +107,7 @@ class _Staging:
 
 
 _STAGING = {}             # device -> the two pinned staging buffers, kept for the life of the process
-_STREAMS = {}             # device -> (download, upload, blob) copy streams, kept for the life of the process
+_STREAMS = {}             # device -> (download, upload) copy streams, kept for the life of the process
 _IO = None
 _TRACE = None             # tools/e2e_timeline.py points this at a list to receive run_streaming's event times
 
@@ -124,18 +124,23 @@ def _io_executor():
 
 
 def _copy_streams(dev):
-    """The three copy streams of run_streaming.  Made once per device and process and touched once here: a HIP stream gets its
-    hardware queue at its first submission, which costs milliseconds -- inference_run pays that on its loader thread."""
+    """The two copy streams of run_streaming, made once per device and process.  Every call pushes a few bytes through each
+    and waits for them: a HIP stream gets its hardware queue at its first submission (milliseconds), and after some
+    milliseconds without work the copy engines take 10-25 ms to come back for the first transfer (measured: the first upload of
+    a run that starts ~15 ms after the previous one ended) -- inference_run pays both on its loader thread while the main
+    thread parses the FASTA."""
     key = str(dev)
     if key not in _STREAMS:
-        streams = tuple(torch.cuda.Stream(dev) for _ in range(3))
-        src = torch.zeros(64, dtype=torch.uint8, pin_memory=True)
-        for st in streams:
-            with torch.cuda.stream(st):
-                src.to(dev, non_blocking=True)
-            st.synchronize()
-        _STREAMS[key] = streams
-    return _STREAMS[key]
+        _STREAMS[key] = (tuple(torch.cuda.Stream(dev) for _ in range(2)), torch.zeros(4096, dtype=torch.uint8, pin_memory=True),
+                         torch.zeros(4096, dtype=torch.uint8, device=dev))
+    streams, host, devbuf = _STREAMS[key]
+    for st in streams:
+        with torch.cuda.stream(st):
+            devbuf.copy_(host, non_blocking=True)
+            host.copy_(devbuf, non_blocking=True)
+    for st in streams:
+        st.synchronize()
+    return streams
 
 
 def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
@@ -162,8 +167,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     pending = None            # the writer job of the previous super-batch
     inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
     # copy_stream: D2H of finished super-batches; up_stream: H2D of the next one (its own stream: never queued behind a D2H that
-    # waits for kernels); blob_stream: exact-size D2H of a finished batch's coded signal (not behind the NEXT batch's small copies)
-    copy_stream, up_stream, blob_stream = _copy_streams(dev)
+    # waits for kernels)
+    copy_stream, up_stream = _copy_streams(dev)
 
     staging = _STAGING.setdefault(str(dev), (_Staging(dev), _Staging(dev)))   # super-batch i + 2 reuses i's buffer: i has been collected by then
     n_launched = 0
@@ -195,64 +200,63 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         total += B
         n_launched += 1
         mark("predict queued")
-        ex = model.engine.export_reads(out["signal"], ins[3], profile_dict["digitisation"], profile_dict["range"],
-                                       profile_dict["offset_mean"], rna=rna, want_pa=False, want_dac=True)
         names = [n for _, n in group]
+        R = len(group)
         main = torch.cuda.current_stream(dev)
-        mark("export queued")
+        # Everything the host needs from this super-batch sits in ONE device buffer and leaves as ONE copy: [read offsets int64
+        # R+1][row offsets int64 N+1 (coded signal only)][payload].  A copy of a few KB would be a shader copy, and no other
+        # wave fits on a CU while the predict kernel holds its whole register file: it would wait for the NEXT super-batch's
+        # kernel to end; a large copy goes through the DMA engines beside it.  The whole capacity is copied (its size is known
+        # without a sync: 16 MB of int16 / 17 MB of coded signal per 32 k chunks) into pinned memory.
+        cap = B * 250
         if gpu_rows:
-            # the signal leaves the GPU StreamVByte-coded (~1.1-1.3 bytes per sample): the small tables first, the blob in
-            # collect() once its size is known
-            svb = model.engine.svb_encode(ex["dac"], ex["offsets"], ins[4], ins[5], gpu_rows[1], gpu_rows[0], B * 250)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                offs_h = torch.empty(ex["offsets"].shape, dtype=torch.int64, pin_memory=True)
-                rows_h = torch.empty(svb["offsets"].shape, dtype=torch.int64, pin_memory=True)
-                offs_h.copy_(ex["offsets"], non_blocking=True)
-                rows_h.copy_(svb["offsets"], non_blocking=True)
-                for t in (ex["offsets"], svb["offsets"], svb["out"]):
-                    t.record_stream(copy_stream)
-                done = torch.cuda.Event()
-                done.record(copy_stream)
-            mark("launched")
-            return names, offs_h, (rows_h, svb["out"], row_read), done
-        # D2H on its own stream, so that it runs beside the next super-batch's kernels instead of queueing behind them.
-        # The whole capacity is copied (its size is known without a sync; 16 MB per 32 k chunks) into pinned memory.
+            N = int(row_read.shape[0])
+            blob_cap = model.engine.svb_capacity(cap, N, gpu_rows[0])
+            head = 8 * (R + 1) + 8 * (N + 1)
+            head += -head % 16
+            buf = torch.empty(head + max(blob_cap, 1), dtype=torch.uint8, device=dev)
+            offs_d = buf[:8 * (R + 1)].view(torch.int64)
+            rows_d = buf[8 * (R + 1): 8 * (R + 1) + 8 * (N + 1)].view(torch.int64)
+            ex = model.engine.export_reads(out["signal"], ins[3], profile_dict["digitisation"], profile_dict["range"],
+                                           profile_dict["offset_mean"], rna=rna, want_pa=False, want_dac=True, out_offsets=offs_d)
+            mark("export queued")
+            # the signal leaves the GPU StreamVByte-coded (~1.1-1.3 bytes per sample)
+            model.engine.svb_encode(ex["dac"], ex["offsets"], ins[4], ins[5], gpu_rows[1], gpu_rows[0], cap, out=buf[head:],
+                                    out_offsets=rows_d)
+        else:
+            head = 8 * (R + 1)
+            head += -head % 16
+            buf = torch.empty(head + 2 * cap, dtype=torch.uint8, device=dev)
+            model.engine.export_reads(out["signal"], ins[3], profile_dict["digitisation"], profile_dict["range"],
+                                      profile_dict["offset_mean"], rna=rna, want_pa=False, want_dac=True,
+                                      out_offsets=buf[:8 * (R + 1)].view(torch.int64), out_dac=buf[head:].view(torch.int16))
+            mark("export queued")
         ready = torch.cuda.Event()
         ready.record(main)
-        with torch.cuda.stream(copy_stream):
+        with torch.cuda.stream(copy_stream):      # its own stream: beside the next super-batch's kernels, not queued behind them
             copy_stream.wait_event(ready)
-            offs_h = torch.empty(ex["offsets"].shape, dtype=torch.int64, pin_memory=True)
-            dac_h = torch.empty(ex["dac"].shape, dtype=torch.int16, pin_memory=True)
-            offs_h.copy_(ex["offsets"], non_blocking=True)
-            dac_h.copy_(ex["dac"], non_blocking=True)
-            ex["offsets"].record_stream(copy_stream)
-            ex["dac"].record_stream(copy_stream)
+            buf_h = torch.empty(buf.shape, dtype=torch.uint8, pin_memory=True)
+            buf_h.copy_(buf, non_blocking=True)
+            buf.record_stream(copy_stream)
             done = torch.cuda.Event()
             done.record(copy_stream)
         mark("launched")
-        return names, offs_h, dac_h, done
+        return names, buf_h, (R, head, row_read if gpu_rows else None), done
 
     def collect(job):
         nonlocal pending
-        ids, offs_h, payload, done = job
+        ids, buf_h, (R, head, row_read), done = job
         mark("wait d2h")
         done.synchronize()
         mark("records")
-        offs = offs_h.numpy()
+        host = buf_h.numpy()
+        offs = host[:8 * (R + 1)].view(np.int64)
         if gpu_rows:
-            rows_h, blob_d, row_read = payload
-            row_offs = rows_h.numpy()
-            with torch.cuda.stream(blob_stream):          # the blob, now that its size is known (its kernels are long done)
-                blob_h = torch.empty(int(row_offs[-1]), dtype=torch.uint8, pin_memory=True)
-                blob_h.copy_(blob_d[: int(row_offs[-1])], non_blocking=True)
-                blob_d.record_stream(blob_stream)
-            blob_stream.synchronize()
-            recs = writer.svb_records(ids, offs, row_read, row_offs, blob_h.numpy())
+            N = int(row_read.shape[0])
+            row_offs = host[8 * (R + 1): 8 * (R + 1) + 8 * (N + 1)].view(np.int64)
+            recs = writer.svb_records(ids, offs, row_read, row_offs, host[head: head + int(row_offs[-1])])
         else:
-            recs = writer.dac_records(ids, payload.numpy()[: int(offs[-1])], offs)
+            recs = writer.dac_records(ids, host[head: head + 2 * int(offs[-1])].view(np.int16), offs)
         mark("wait writer")
         if pending is not None:
             pending.result()
@@ -345,10 +349,9 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-load")
 
     def load(**kw):
-        m = seq2squiggle.load_from_checkpoint(**kw)
         if streaming:
-            _copy_streams(m.device)
-        return m
+            _copy_streams(torch.device("cuda", int(kw["device"])))
+        return seq2squiggle.load_from_checkpoint(**kw)
     loading = loader.submit(
         load, checkpoint_path=saved_weights, out_writer=writer, dwell_mean=dwell_mean,
         dwell_std=dwell_std, noise_std=noise_std, noise_sampling=noise_sampling, duration_sampling=duration_sampling,
