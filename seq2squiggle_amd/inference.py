@@ -143,6 +143,38 @@ def _copy_streams(dev):
     return streams
 
 
+def super_batches(reads: Iterable[Tuple[str, str]], k: int, max_chunks: int):
+    """Whole reads grouped into super-batches of about max_chunks chunks (reads too short for one chunk are dropped).  The first
+    groups are short (1/8, 1/4, 1/2 of max_chunks): the GPU starts as soon as a few reads exist, and the host, which prepares a
+    chunk faster than the GPU predicts one, is ahead from then on.  The last ones shrink again when the iterable says how many
+    reads are left (operator.length_hint: lists, utils.CountedReads): what remains after the GPU's last kernel is then the
+    D2H + compression + write of a small super-batch only."""
+    import operator
+    floor = max(max_chunks // 8, 1)
+    ramp = want = floor
+    seen_reads = seen_chunks = 0
+    group, n = [], 0
+    reads = iter(reads)
+    for seq, name in reads:
+        c = _n_chunks(len(seq), k)
+        if c == 0:
+            logger.debug(f"Skipped read {name}.")
+            continue
+        group.append((seq, name))
+        n += c
+        seen_reads += 1
+        seen_chunks += c
+        if n >= want:
+            yield group
+            group, n = [], 0
+            ramp = want = min(2 * ramp, max_chunks)
+            left = operator.length_hint(reads, 0) * seen_chunks // seen_reads      # chunks still to come; 0: not known
+            if 0 < left < 2 * want:
+                want = max(left // 2, floor)
+    if group:
+        yield group
+
+
 def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict: dict, profile_name: str,
                   max_chunks: int = 32768, trace: list = None) -> int:
     """The predict loop without per-chunk Python objects: whole reads are grouped into super-batches of about
@@ -269,37 +301,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         pending = io.submit(job_)
 
     try:
-        group, n = [], 0
-        # The first super-batches are short (1/8, 1/4, 1/2 of max_chunks): the GPU starts as soon as a few reads exist, and the
-        # host, which prepares a chunk faster than the GPU predicts one, is ahead from then on.  The last ones shrink again when
-        # the iterable says how many reads are left (operator.length_hint): what remains after the GPU's last kernel is the
-        # D2H + compression + write of the final super-batch only.
-        import operator
-        floor = max(max_chunks // 8, 1)
-        ramp = want = floor
-        seen_reads = seen_chunks = 0
-        reads = iter(reads)
         mark("first read wanted")
-        for seq, name in reads:
-            c = _n_chunks(len(seq), k)
-            if c == 0:
-                logger.debug(f"Skipped read {name}.")
-                continue
-            group.append((seq, name))
-            n += c
-            seen_reads += 1
-            seen_chunks += c
-            if n >= want:
-                job = launch(group)
-                if inflight is not None:
-                    collect(inflight)
-                inflight = job
-                group, n = [], 0
-                ramp = want = min(2 * ramp, max_chunks)
-                left = operator.length_hint(reads, 0) * seen_chunks // seen_reads      # chunks still to come; 0: not known
-                if 0 < left < 2 * want:
-                    want = max(left // 2, floor)
-        if group:
+        for group in super_batches(reads, k, max_chunks):
             job = launch(group)
             if inflight is not None:
                 collect(inflight)

@@ -488,3 +488,47 @@ def test_cli_surface():
     assert cfg["seq_kmer"] == 9 and cfg["dmodel"] == 64 and cfg["max_signal_len"] == 250 and cfg["scaling_max_value"] == 165.0
     with pytest.raises(FileNotFoundError):
         set_config("/nonexistent.yaml")
+
+
+def test_super_batches_ramp_and_taper():
+    """run_streaming's grouping policy: every read exactly once and in order, short first groups, full-size middle, and -- when
+    the iterable knows its length -- a tail that shrinks to the floor; a plain generator (no length hint) keeps full groups."""
+    from seq2squiggle_amd.inference import super_batches, _n_chunks
+    from seq2squiggle_amd.utils import CountedReads
+    rng = np.random.default_rng(2)
+    reads = [("A" * int(L), f"r{i}") for i, L in enumerate(rng.integers(5, 9000, 800))]
+    reads[3] = ("ACG", "too-short")
+    live = [r for r in reads if _n_chunks(len(r[0]), 9) > 0]
+    for source, knows in ((lambda: list(reads), True), (lambda: CountedReads(iter(reads), len(reads)), True),
+                          (lambda: (r for r in reads), False)):
+        groups = list(super_batches(source(), 9, 32768))
+        assert [r for g in groups for r in g] == live
+        sizes = [sum(_n_chunks(len(s), 9) for s, _ in g) for g in groups]
+        assert 4096 <= sizes[0] < 4096 + 600 and 8192 <= sizes[1] < 8192 + 600 and 16384 <= sizes[2] < 16384 + 600
+        assert max(sizes) < 32768 + 600
+        if knows:
+            assert sizes[-1] < 8192 and sizes[-2] <= 16384 + 600           # the tail shrinks
+        else:
+            assert all(sz >= 32768 for sz in sizes[3:-1])
+    assert list(super_batches([], 9, 1024)) == [] and list(super_batches([("AC", "x")], 9, 1024)) == []
+
+
+def test_cpu_share_honours_quota_and_ranks(monkeypatch):
+    import builtins, io
+    real_open = builtins.open
+
+    def fake(quota):
+        def opener(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                return io.StringIO(quota)
+            return real_open(path, *a, **k)
+        return opener
+    cores = len(os.sched_getaffinity(0))
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setattr(builtins, "open", fake("200000 100000\n"))
+    assert signal_io.cpu_share() == min(2, cores)
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert signal_io.cpu_share() == min(128, cores)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert signal_io.cpu_share() == max(1, min(16, cores) // 8)
