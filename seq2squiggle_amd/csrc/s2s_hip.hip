@@ -429,7 +429,8 @@ __device__ __forceinline__ void dec_emit(const ModelDev& M, const float ys, cons
 // to 8 * FNQ: wave w runs the one-wave frontend of chunks FNQ*w .. FNQ*w+FNQ-1 of the group (their encoder K/V in a slice of
 // the decoder's K/V region, dead between chunks), then all 8 waves decode the group's chunks one after the other.  The
 // frontend outputs of a group (4.2 KB per chunk) wait in the workgroup's own slots of `handoff` -- rewritten every group by the
-// CU that reads them back, so they live in that XCD's L2 and HBM sees them only as an occasional write-back.
+// CU that reads them back, so the reads hit that XCD's L2.  The dirty lines do get written back once per group, though: an XCD's
+// L2 keeps about 1.5 MB of rewritten data (tools/probes/l2_writeback_probe.hip) and 32 workgroups x 16 slots are 2.2 MB.
 template <int MODE> struct Fused {
     static constexpr int FMODE = (MODE == 3) ? 1 : MODE;          // the reduced-precision decoder keeps the f16x3 frontend
     static constexpr int FNQ = (FMODE == 1) ? 2 : 1;              // chunks per frontend wave
