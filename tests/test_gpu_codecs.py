@@ -98,3 +98,42 @@ def test_bad_arguments(eng):
         eng.svb_encode(z.float(), o, i0, i0, 100, 16, 4)
     r = eng.svb_encode(z, o, i0[:0], i0[:0], 100, 16, 0)         # no rows: a single zero offset
     assert r["offsets"].cpu().tolist() == [0]
+
+
+def test_outputs_into_one_caller_buffer(eng):
+    """The streaming path's layout: read offsets, row offsets and the coded signal are views of ONE device buffer (it leaves
+    the GPU as a single DMA copy).  Same bytes as with library-allocated outputs; undersized or mistyped views are refused."""
+    rng = np.random.default_rng(4)
+    B = 40
+    sig = torch.from_numpy(np.where(rng.random((B, 250)) < 0.1, 0.0, rng.normal(90, 15, (B, 250))).astype(np.float32)).cuda()
+    first = torch.tensor([0, 7, 7, 25, 40], dtype=torch.int32).cuda()            # four reads, the second one empty
+    R = 4
+    ref = eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, want_dac=True)
+    rr = torch.tensor([0, 1, 2, 3], dtype=torch.int32).cuda()
+    ri = torch.zeros(4, dtype=torch.int32).cuda()
+    ref_svb = eng.svb_encode(ref["dac"], ref["offsets"], rr, ri, 1 << 40, 32, B * 250)
+    cap = eng.svb_capacity(B * 250, 4, 32)
+    head = 8 * (R + 1) + 8 * 5
+    head += -head % 16
+    buf = torch.zeros(head + cap, dtype=torch.uint8, device="cuda")
+    offs_v, rows_v = buf[:8 * (R + 1)].view(torch.int64), buf[8 * (R + 1): 8 * (R + 1) + 40].view(torch.int64)
+    ex = eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, want_dac=True, out_offsets=offs_v)
+    got = eng.svb_encode(ex["dac"], ex["offsets"], rr, ri, 1 << 40, 32, B * 250, out=buf[head:], out_offsets=rows_v)
+    assert got["out"].data_ptr() == buf[head:].data_ptr() and ex["offsets"].data_ptr() == buf.data_ptr()
+    host = buf.cpu().numpy()
+    n = int(ref_svb["offsets"][-1])
+    assert np.array_equal(host[:8 * (R + 1)].view(np.int64), ref["offsets"].cpu().numpy())
+    assert np.array_equal(host[8 * (R + 1): 8 * (R + 1) + 40].view(np.int64), ref_svb["offsets"].cpu().numpy())
+    assert np.array_equal(host[head: head + n], ref_svb["out"][:n].cpu().numpy())
+    # int16 samples straight into the buffer (the BLOW5 path)
+    buf2 = torch.zeros(48 + 2 * B * 250, dtype=torch.uint8, device="cuda")
+    ex2 = eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, want_dac=True,
+                           out_offsets=buf2[:40].view(torch.int64), out_dac=buf2[48:].view(torch.int16))
+    m = int(ref["offsets"][-1])
+    assert torch.equal(ex2["dac"][:m], ref["dac"][:m]) and ex2["dac"].data_ptr() == buf2[48:].data_ptr()
+    with pytest.raises(ValueError):
+        eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, out_offsets=buf2[:32].view(torch.int64))
+    with pytest.raises(ValueError):
+        eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, out_dac=buf2[48:1000].view(torch.int16))
+    with pytest.raises(ValueError):
+        eng.svb_encode(ex["dac"], ex["offsets"], rr, ri, 1 << 40, 32, B * 250, out=buf[head: head + 100])
