@@ -48,6 +48,11 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define SB_GEMM()
 #endif
 #define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#ifndef S2S_ATT32
+#define S2S_ATT32 1
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMAW(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 struct HL { h8 hi, lo; };
 
@@ -122,10 +127,17 @@ template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
     // (The natural key order needed two b64 reads, which hipcc fuses into ds_read2_b64: banked mod 32, 2-way conflicts on
     // every access -- the 11,264 SQ_LDS_BANK_CONFLICT cycles per chunk of profiles/r01.)  Odd NKT: natural order.
     static constexpr bool V128 = (NKT % 2) == 0;
-    static constexpr int VS = V128 ? KEYS + 16 : KEYS + 8;
+    // ATT32 (the decoder with S2S_ATT32): the attention core runs on v_mfma_f32_32x32x16_f16 (softmax_pv32).  A V^T row is then
+    // stored as [16-key step][lane half h][8 halves] -- keys 4h..4h+3 and 8+4h..8+4h+3 of the step: the 8 k-slots a lane half feeds
+    // -- 264 halves = 132 dwords == 4 (mod 64): the 16 rows of a ds_read_b128 land in 16 distinct 4-dword bank slots.  Two
+    // constant rows follow the V region (all ones: the A-operand row that makes the MFMA add up P; all zeros: rows 17-31 of that
+    // operand and the unused k-slots of the second Q operand), written once per kernel (att32_consts).
+    static constexpr bool ATT32 = S2S_ATT32 && NQ == 2 && NKT == 16;
+    static constexpr int VS = ATT32 ? KEYS + 8 : V128 ? KEYS + 16 : KEYS + 8;
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
+    static constexpr int C_BYTES = ATT32 ? 2 * VS * 2 : 0;
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
-    static constexpr int BYTES = K_BYTES + V_BYTES + WAVES * Q_WAVE_BYTES;
+    static constexpr int BYTES = K_BYTES + V_BYTES + C_BYTES + WAVES * Q_WAVE_BYTES;
 };
 
 // acc[q] += W_unit * x[q]: one 16-row m-tile, K = 64 as two k-blocks, three products each.
@@ -296,6 +308,131 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
     }
 }
 
+// ---- The decoder's attention core on the 32x32x16 MFMA (S2S_ATT32): Softmax(Q K^T) V of one head for the wave's 32 queries.
+// A SIMD issues matrix and vector instructions through one port, a well-spaced MFMA holds it for ~8 cycles whatever its shape
+// (tools/probes/issue_probe.hip), and the attention loop is bound by exactly that port: the 32x32x16 shape does the same flops
+// in half the instructions.  Lane (h = lane >> 5, n = lane & 31); an accumulator tile (f32x16) holds rows (r & 3) + 8 (r >> 2) + 4h
+// of column n in register r, so registers 8s .. 8s+7 of a score tile ARE the lane's 8 k-slots of 16-key step s of the P.V MFMA:
+//   scores (32 keys x 32 queries): A = K row of key 32t + n': [K_hi | K_lo] over the lane halves; B1 = [Q_hi | Q_hi], B2 = [Q_lo | 0]
+//     -> K_hi.Q_hi + K_lo.Q_hi + K_hi.Q_lo in two MFMAs, the shift -m as the C operand of the first;
+//   P.V (16 keys per MFMA): A rows 0-7 V_hi d, 8-15 V_lo d, 16 ones, 17-31 zeros (constant LDS rows); B = P_hi, then P_lo, into ONE
+//     accumulator: O[d] = row d + row 8+d is an in-lane add and row 16 is the softmax row sum (V_lo.P_lo rides along: 2^-22).
+// 52 MFMAs per head instead of 104, no cross-lane traffic between the score tile and the P.V operand.  SAFE as in softmax_pv.
+__device__ __forceinline__ float max_h(float v) {              // over the two lane halves
+    const unsigned u = __float_as_uint(v);
+    auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+__device__ __forceinline__ float sum_h(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+template <int TV, bool SAFE, bool LO>
+__device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ vp, const h8 qb1, const h8 qb2,
+                                             const float one, const int h, f32x16& O) {
+    constexpr int NT = 8;                                       // key tiles of 32
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto k_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp + 32 * t * 8); };
+    auto scores = [&](const h8 ka, const f32x16 c0) { return MFMAW(ka, qb2, MFMAW(ka, qb1, c0)); };
+    O = zero16;
+    auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
+    auto mask_last = [&](f32x16& t) {                                    // phantom keys -> -inf: rows 224 + .. >= TV of the last tile
+        if (TV < 256) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (224 + (r & 3) + 8 * (r >> 2) + 4 * h >= TV) t[r] = -__builtin_inff();
+        }
+    };
+    auto pv = [&](const f32x16& t, const h8 (&va)[2]) {                   // O += [V_hi; V_lo; 1] . exp2(t), 16 keys per MFMA
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+            exp_split4<LO>(f32x4{t[8 * st], t[8 * st + 1], t[8 * st + 2], t[8 * st + 3]}, one, h0, h1, l0, l1);
+            exp_split4<LO>(f32x4{t[8 * st + 4], t[8 * st + 5], t[8 * st + 6], t[8 * st + 7]}, one, h2_, h3, l2, l3);
+            O = MFMAW(va[st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
+            if (LO) O = MFMAW(va[st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
+        }
+    };
+    f32x16 negm = zero16;
+    if constexpr (!SAFE) {
+        // fast path: the shift is pass 0's column max (+ head-room), later passes compute no max at all.  Two tiles (64 keys) per
+        // pass, as straight-line code.  (Measured: issuing tile t+1's score MFMAs ahead of tile t's exponentials by hand -- no
+        // s_nop in front of the first exponential any more -- is 1.3 % SLOWER than leaving the pass to the compiler.)
+#pragma unroll
+        for (int h2 = 0; h2 < NT / 2; ++h2) {
+            h8 ka[2], va[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ka[i] = k_of(2 * h2 + i);
+                va[i][0] = v_of(2 * h2 + i, 0); va[i][1] = v_of(2 * h2 + i, 1);
+            }
+            SB_ATT();
+            f32x16 sc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm);     // (pass 0: negm = 0)
+            if (h2 == NT / 2 - 1) mask_last(sc[1]);
+            if (h2 == 0) {
+                float mh = sc[0][0];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mh = fmaxf(mh, sc[i][r]);
+                mh = max_h(mh) + S2S_SHIFT_BIAS;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -mh;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm); // "score - m" from the matrix cores again
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+                    exp_split4<LO>(f32x4{sc[i][8 * st], sc[i][8 * st + 1], sc[i][8 * st + 2], sc[i][8 * st + 3]}, one, h0, h1, l0, l1);
+                    exp_split4<LO>(f32x4{sc[i][8 * st + 4], sc[i][8 * st + 5], sc[i][8 * st + 6], sc[i][8 * st + 7]}, one, h2_, h3, l2, l3);
+                    O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
+                    if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
+                }
+        }
+    } else {
+        float m = 0.0f;
+#pragma unroll
+        for (int h2 = 0; h2 < NT / 2; ++h2) {                            // a textbook online softmax, 64 keys per pass
+            h8 ka[2], va[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ka[i] = k_of(2 * h2 + i);
+                va[i][0] = v_of(2 * h2 + i, 0); va[i][1] = v_of(2 * h2 + i, 1);
+            }
+            f32x16 sc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm);     // (pass 0: negm = 0)
+            if (h2 == NT / 2 - 1) mask_last(sc[1]);
+            float mh = sc[0][0];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mh = fmaxf(mh, sc[i][r]);
+            mh = max_h(mh);
+            const float delta = (h2 == 0) ? mh : fmaxf(mh, 0.0f);         // raise the running max, rescale the sums
+            if (h2 > 0) O *= __builtin_amdgcn_exp2f(-delta);
+            m += delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { sc[i] -= delta; pv(sc[i], va[i]); }
+        }
+    }
+}
+// the constant rows behind the V region (see AttnLdsH): called once per kernel, before the first barrier
+template <class G> __device__ __forceinline__ void att32_consts(char* __restrict__ lds, const int tid, const int nthreads) {
+    if constexpr (G::ATT32) {
+        _Float16* cr = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES);
+        for (int i = tid; i < 2 * G::VS; i += nthreads) cr[i] = (i < G::VS) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+}
+
 // A weight unit of the f16 streams: [kb0 hi][kb0 lo][kb1 hi][kb1 lo] (4 KiB), or, for the single-product mode, the hi-only
 // stream [kb0 hi][kb1 hi] (2 KiB) loaded into the same even slots.
 template <bool LO>
@@ -333,7 +470,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
     _Float16* __restrict__ Vl = reinterpret_cast<_Float16*>(lds + G::K_BYTES);
-    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + wave * G::Q_WAVE_BYTES);
+    _Float16* __restrict__ Ql = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES + G::C_BYTES + wave * G::Q_WAVE_BYTES);
     constexpr int UF = LO ? 1024 : 512;             // floats per weight unit: hi+lo fragments, or the hi-only stream
     const float* ws = W + (LO ? L.stream_h : L.stream_f) + lane * 4;
     f32x4 fa[4], fb[4];
@@ -379,7 +516,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
             split4<LO>(av[q], one, hi, lo);                           // 4 consecutive keys of one V^T row: one b64 store each
-            const int vcol = G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
+            const int vcol = G::ATT32 ? 16 * T + 8 * (g & 1) + 4 * (g >> 1)
+                           : G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
             *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
         }
@@ -424,6 +562,45 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 *reinterpret_cast<h4*>(Ql + ((((g >> 1) * NQ + q) * 2 + 0) * 16 + c) * 8 + 4 * (g & 1)) = hi;   // [head of the pair][q][hi|lo][c][8 d]
                 *reinterpret_cast<h4*>(Ql + ((((g >> 1) * NQ + q) * 2 + 1) * 16 + c) * 8 + 4 * (g & 1)) = lo;
             }
+            if constexpr (G::ATT32) {
+                // both heads of the pair on the 32x32x16 core; a head's output (4 d per lane) goes through its own, by then dead,
+                // half of the wave's Q scratch into the pair-tile layout the fc operand wants (row 4g+r: head g >> 1, d = 4 (g & 1) + r)
+                const int hl = lane >> 5, n = lane & 31;
+                const _Float16* const crow = Vl + 8 * 16 * G::VS;         // [ones row][zeros row]
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int head = 2 * p + hh;
+                    const _Float16* qrow = Ql + (((hh * NQ + (n >> 4)) * 2 + 0) * 16 + (n & 15)) * 8;      // [head of the pair][q][hi|lo][c][8 d]
+                    const h8 qb1 = *reinterpret_cast<const h8*>(qrow);
+                    const h8 qb2 = *reinterpret_cast<const h8*>(hl ? crow + G::VS : qrow + 16 * 8);
+                    const _Float16* kp = Kl + ((head * 2 + hl) * G::KEYS + n) * 8;                         // K_hi rows for h = 0, K_lo for h = 1
+                    const _Float16* vp = (n < 16 ? Vl + (head * 16 + n) * G::VS : n == 16 ? crow : crow + G::VS) + 8 * hl;
+                    f32x16 O;
+                    softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, vp, qb1, qb2, one, hl, O);
+                    float lsum = sum_h(O[8]);                              // row 16 lives in the lower lane half
+#if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)
+                    {
+                        const bool redo = __any(!(lsum <= 3.0e38f));       // inf or NaN row sum: some P_hi left the f16 range
+#ifdef S2S_DIAG
+                        if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
+#endif
+                        if (__builtin_expect(redo, 0)) {
+                            softmax_pv32<TV, true, LO>(kp, vp, qb1, qb2, one, hl, O);
+                            lsum = sum_h(O[8]);
+                        }
+                    }
+#endif
+                    const float inv = __builtin_amdgcn_rcpf(lsum);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (O[r] + O[4 + r]) * inv;          // V_hi row d + V_lo row d, d = 4h + r
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Ql + hh * (NQ * 2 * 16 * 8)) + n * 8 + 4 * hl) = o;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    opair[pp][q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Ql + (g >> 1) * (NQ * 2 * 16 * 8)) +
+                                                                   (q * 16 + c) * 8 + 4 * (g & 1));
+            } else {
             // The pair's fc operand takes head 2p from lanes g < 2 and head 2p+1 from lanes g >= 2.  Head 2p's output is
             // parked, for the lanes that will use it, in the first half of the wave's Q scratch (head 2p's Q^T, dead once
             // qb has been read) instead of eight more live registers through the second head's softmax.
@@ -471,6 +648,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) {                 // pair tile: row 4g+r
                 const f32x4 o0 = *reinterpret_cast<const f32x4*>(Ql + (q * 32 + (lane & 31)) * 8);
                 opair[pp][q] = (g < 2) ? o0 : ohead1[q];
+            }
             }
         }
         // ---- fc, k-block u (the 4 heads just finished): acc += Wfc[:, 32u : 32u+32] * O^T

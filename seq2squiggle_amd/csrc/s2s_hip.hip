@@ -460,6 +460,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nb = S2S_T_ENC + M.k - 1;
+    if constexpr (MODE != 0) att32_consts<AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>>(lds_raw, threadIdx.x, DEC_WAVES * 64);   // (visible after the group loop's first barrier)
     float* const slot0 = handoff + (size_t)blockIdx.x * S2S_MAX_GROUP * S2S_SLOT_FLOATS;
     const int lo = (int)((long long)blockIdx.x * n_chunks / gridDim.x), hi = (int)((long long)(blockIdx.x + 1) * n_chunks / gridDim.x);
 #pragma unroll 1
