@@ -51,6 +51,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ATT32
 #define S2S_ATT32 1
 #endif
+#ifndef S2S_ATT32_MSLOT
+#define S2S_ATT32_MSLOT 1
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMAW(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
@@ -135,7 +138,7 @@ template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
     static constexpr bool ATT32 = S2S_ATT32 && NQ == 2 && NKT == 16;
     static constexpr int VS = ATT32 ? KEYS + 8 : V128 ? KEYS + 16 : KEYS + 8;
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
-    static constexpr int C_BYTES = ATT32 ? 2 * VS * 2 : 0;
+    static constexpr int C_BYTES = ATT32 ? 3 * VS * 2 : 0;         // rows: ones | zeros | {1, 1, 0, 0, 0, 0, 0, 0} repeated
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
     static constexpr int BYTES = K_BYTES + V_BYTES + C_BYTES + WAVES * Q_WAVE_BYTES;
 };
@@ -329,8 +332,8 @@ __device__ __forceinline__ float sum_h(float v) {
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 template <int TV, bool SAFE, bool LO>
-__device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ vp, const h8 qb1, const h8 qb2,
-                                             const float one, const int h, f32x16& O) {
+__device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
+                                             const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
     constexpr int NT = 8;                                       // key tiles of 32
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto k_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp + 32 * t * 8); };
@@ -355,6 +358,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
         }
     };
     f32x16 negm = zero16;
+    h8 qb2m = qb2;
     if constexpr (!SAFE) {
         // fast path: the shift is pass 0's column max (+ head-room), later passes compute no max at all.  Two tiles (64 keys) per
         // pass, as straight-line code.  (Measured: issuing tile t+1's score MFMAs ahead of tile t's exponentials by hand -- no
@@ -368,6 +372,32 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
                 va[i][0] = v_of(2 * h2 + i, 0); va[i][1] = v_of(2 * h2 + i, 1);
             }
             SB_ATT();
+#if S2S_ATT32_MSLOT
+            // the shift rides in the second score MFMA: its A operand carries {1, 1, 0..} instead of K_lo in the upper lane half's
+            // k-slots (kp2: a constant LDS row there, the K_hi row below), its B operand {-m_hi, -m_lo, 0..} where Q_lo has none
+            h8 kb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) kb[i] = *reinterpret_cast<const h8*>(kp2 + (2 * h2 + i) * (h ? 0 : 32 * 8));
+            f32x16 sc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
+            if (h2 == NT / 2 - 1) mask_last(sc[1]);
+            if (h2 == 0) {
+                float mh = sc[0][0];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mh = fmaxf(mh, sc[i][r]);
+                const float nm = -(max_h(mh) + S2S_SHIFT_BIAS);
+                const _Float16 nh = (_Float16)nm;
+                const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, (_Float16)(nm - (float)nh)}));
+                uv4 q2 = __builtin_bit_cast(uv4, qb2);
+                q2[0] = h ? pk : q2[0];
+                qb2m = __builtin_bit_cast(h8, q2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
+            }
+#else
             f32x16 sc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm);     // (pass 0: negm = 0)
@@ -384,6 +414,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 #pragma unroll
                 for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm); // "score - m" from the matrix cores again
             }
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -429,7 +460,8 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 template <class G> __device__ __forceinline__ void att32_consts(char* __restrict__ lds, const int tid, const int nthreads) {
     if constexpr (G::ATT32) {
         _Float16* cr = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES);
-        for (int i = tid; i < 2 * G::VS; i += nthreads) cr[i] = (i < G::VS) ? (_Float16)1.0f : (_Float16)0.0f;
+        for (int i = tid; i < 3 * G::VS; i += nthreads)
+            cr[i] = (i < G::VS || (i >= 2 * G::VS && ((i - 2 * G::VS) & 7) < 2)) ? (_Float16)1.0f : (_Float16)0.0f;
     }
 }
 
@@ -574,9 +606,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     const h8 qb1 = *reinterpret_cast<const h8*>(qrow);
                     const h8 qb2 = *reinterpret_cast<const h8*>(hl ? crow + G::VS : qrow + 16 * 8);
                     const _Float16* kp = Kl + ((head * 2 + hl) * G::KEYS + n) * 8;                         // K_hi rows for h = 0, K_lo for h = 1
+                    const _Float16* kp2 = hl ? crow + 2 * G::VS : kp;                                       // (second score MFMA: K_hi | {1, 1, 0..})
                     const _Float16* vp = (n < 16 ? Vl + (head * 16 + n) * G::VS : n == 16 ? crow : crow + G::VS) + 8 * hl;
                     f32x16 O;
-                    softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, vp, qb1, qb2, one, hl, O);
+                    softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
                     float lsum = sum_h(O[8]);                              // row 16 lives in the lower lane half
 #if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)
                     {
@@ -585,7 +618,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
 #endif
                         if (__builtin_expect(redo, 0)) {
-                            softmax_pv32<TV, true, LO>(kp, vp, qb1, qb2, one, hl, O);
+                            softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
                             lsum = sum_h(O[8]);
                         }
                     }
