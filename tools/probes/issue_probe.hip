@@ -34,7 +34,9 @@ __device__ __forceinline__ float body(float seed, long long* cycles) {
                 const int r = (s * (NV / 8) + k) & 15;
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[r]) : "v"(seed));
                 else if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
-                else asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[r]) : "v"(seed));
+                else if (KIND == 2) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[r]) : "v"(seed));
+                else if (KIND == 3) asm volatile("v_dot2c_f32_f16_e32 %0, -1.0, %1" : "+v"(v[r]) : "v"(seed));
+                else asm volatile("v_fma_mixlo_f16 %0, %0, 1.0, %1 op_sel_hi:[0,0,1]" : "+v"(v[r]) : "v"(seed));
             }
         }
     }
@@ -94,6 +96,14 @@ int main() {
     run<1, 32, 1, 0, 0>("1 wave/SIMD: 8 mfma16 + 32 v_exp interleaved", 256);
     run<1, 16, 1, 0, 0>("1 wave/SIMD: 8 mfma16 + 16 v_exp interleaved", 256);
     run<1, 32, 1, 1, 0>("1 wave/SIMD: 4 mfma32 + 32 v_exp interleaved", 256);
+    run<0, 32, 3, 0, 0>("1 wave/SIMD: 32 v_dot2c alone", 256);
+    run<0, 32, 4, 0, 0>("1 wave/SIMD: 32 v_fma_mixlo alone", 256);
+    run<1, 32, 3, 0, 0>("1 wave/SIMD: 8 mfma16 + 32 v_dot2c interleaved", 256);
+    run<1, 32, 4, 0, 0>("1 wave/SIMD: 8 mfma16 + 32 v_fma_mixlo interleaved", 256);
+    run<1, 32, 3, 1, 0>("1 wave/SIMD: 4 mfma32 + 32 v_dot2c interleaved", 256);
+    run<1, 32, 4, 1, 0>("1 wave/SIMD: 4 mfma32 + 32 v_fma_mixlo interleaved", 256);
+    run<1, 32, 0, 1, 0>("1 wave/SIMD: 4 mfma32 + 32 v_fma (again)", 256);
+    run<1, 16, 4, 1, 0>("1 wave/SIMD: 4 mfma32 + 16 v_fma_mixlo interleaved", 256);
     // two waves per SIMD (512 threads)
     run<1, 0, 0, 0, 0>("2 waves/SIMD: 8 mfma16 alone (each)", 512);
     run<0, 32, 0, 0, 0>("2 waves/SIMD: 32 v_fma alone (each)", 512);

@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void NAME(float seed, float* sink, long long* 
     const long long t0 = __builtin_readcyclecounter();                                            \
     _Pragma("unroll 1") for (int it = 0; it < ITERS; ++it) {                                      \
         _Pragma("unroll") for (int rep = 0; rep < 2; ++rep) {                                     \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile(ASM : "+v"(v[r]) : "v"(w[r]), "v"(z[(r + 5) & 15])); \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile(ASM : "+v"(v[r]), "+v"(w[r]) : "v"(z[(r + 5) & 15])); \
         }                                                                                         \
     }                                                                                             \
     const long long t1 = __builtin_readcyclecounter();                                            \
@@ -30,6 +30,15 @@ KERNEL(k_mov, "v_mov_b32_e32 %0, %1")
 KERNEL(k_cvt_pk, "v_cvt_pk_f16_f32 %0, %1, %2")
 KERNEL(k_mixlo, "v_fma_mixlo_f16 %0, %1, %2, %0 op_sel_hi:[0,0,1]")
 KERNEL(k_mixhi, "v_fma_mixhi_f16 %0, %1, %2, %0 op_sel_hi:[0,0,1]")
+KERNEL(k_dot2_f32_f16, "v_dot2_f32_f16 %0, %1, %2, %0")
+KERNEL(k_dot2c_f32_f16, "v_dot2c_f32_f16_e32 %0, %1, %2")
+KERNEL(k_dot2c_literal, "v_dot2c_f32_f16_e32 %0, 0xbc000000, %1")
+KERNEL(k_dot2c_inline, "v_dot2c_f32_f16_e32 %0, -1.0, %1")
+KERNEL(k_add_literal, "v_add_f32_e32 %0, 0x3fc00001, %0")
+KERNEL(k_split_dot2, "v_cvt_pk_f16_f32 %1, %0, %2\n v_dot2c_f32_f16_e32 %0, -1.0, %1\n v_cvt_pk_f16_f32 %0, %0, %2")
+KERNEL(k_split_mix, "v_cvt_pk_f16_f32 %1, %0, %2\n v_fma_mixlo_f16 %0, %0, 1.0, -%1 op_sel_hi:[0,0,1]")
+KERNEL(k_cvt_f32_f16, "v_cvt_f32_f16_e32 %0, %1")
+KERNEL(k_pk_add_f16, "v_pk_add_f16 %0, %1, %2")
 KERNEL(k_exp, "v_exp_f32_e32 %0, %1")
 KERNEL(k_rcp, "v_rcp_f32_e32 %0, %1")
 KERNEL(k_max3, "v_max3_f32 %0, %1, %2, %0")
@@ -61,7 +70,7 @@ int main() {
     float* sink; long long* out; hipMalloc(&sink, 4); hipMalloc(&out, 64);
     double base = -1;
     RUN(k_empty); RUN(k_add_e32); RUN(k_max_e32); RUN(k_mul_e32); RUN(k_fmac_e32); RUN(k_fma_3src); RUN(k_fma_same); RUN(k_mov);
-    RUN(k_cvt_pk); RUN(k_mixlo); RUN(k_mixhi); RUN(k_exp); RUN(k_rcp); RUN(k_max3); RUN(k_xor); RUN(k_cndmask); RUN(k_perm32swap);
+    RUN(k_cvt_pk); RUN(k_dot2_f32_f16); RUN(k_dot2c_f32_f16); RUN(k_dot2c_literal); RUN(k_dot2c_inline); RUN(k_add_literal); RUN(k_split_dot2); RUN(k_split_mix); RUN(k_cvt_f32_f16); RUN(k_pk_add_f16); RUN(k_mixlo); RUN(k_mixhi); RUN(k_exp); RUN(k_rcp); RUN(k_max3); RUN(k_xor); RUN(k_cndmask); RUN(k_perm32swap);
     RUN(k_perm16swap); RUN(k_readlane_free); RUN(k_pk_fma);
     return 0;
 }
