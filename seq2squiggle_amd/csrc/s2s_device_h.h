@@ -132,9 +132,10 @@ template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
     static constexpr bool V128 = (NKT % 2) == 0;
     // ATT32 (the decoder with S2S_ATT32): the attention core runs on v_mfma_f32_32x32x16_f16 (softmax_pv32).  A V^T row is then
     // stored as [16-key step][lane half h][8 halves] -- keys 4h..4h+3 and 8+4h..8+4h+3 of the step: the 8 k-slots a lane half feeds
-    // -- 264 halves = 132 dwords == 4 (mod 64): the 16 rows of a ds_read_b128 land in 16 distinct 4-dword bank slots.  Two
+    // -- 264 halves = 132 dwords == 4 (mod 64): the 16 rows of a ds_read_b128 land in 16 distinct 4-dword bank slots.  Three
     // constant rows follow the V region (all ones: the A-operand row that makes the MFMA add up P; all zeros: rows 17-31 of that
-    // operand and the unused k-slots of the second Q operand), written once per kernel (att32_consts).
+    // operand and the unused k-slots of the second Q operand; {1, 1, 0, 0, 0, 0, 0, 0} repeated: the k-slots of the second score
+    // MFMA's A operand that take the softmax shift), written once per kernel (att32_consts).
     static constexpr bool ATT32 = S2S_ATT32 && NQ == 2 && NKT == 16;
     static constexpr int VS = ATT32 ? KEYS + 8 : V128 ? KEYS + 16 : KEYS + 8;
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
@@ -316,8 +317,9 @@ __device__ __forceinline__ void softmax_pv(const _Float16* __restrict__ kp, cons
 // (tools/probes/issue_probe.hip), and the attention loop is bound by exactly that port: the 32x32x16 shape does the same flops
 // in half the instructions.  Lane (h = lane >> 5, n = lane & 31); an accumulator tile (f32x16) holds rows (r & 3) + 8 (r >> 2) + 4h
 // of column n in register r, so registers 8s .. 8s+7 of a score tile ARE the lane's 8 k-slots of 16-key step s of the P.V MFMA:
-//   scores (32 keys x 32 queries): A = K row of key 32t + n': [K_hi | K_lo] over the lane halves; B1 = [Q_hi | Q_hi], B2 = [Q_lo | 0]
-//     -> K_hi.Q_hi + K_lo.Q_hi + K_hi.Q_lo in two MFMAs, the shift -m as the C operand of the first;
+//   scores (32 keys x 32 queries): A = K row of key 32t + n': [K_hi | K_lo] over the lane halves, B1 = [Q_hi | Q_hi]; then
+//     A2 = [K_hi | 1, 1, 0..] (kp2: a constant LDS row in the upper half), B2 = [Q_lo | -m_hi, -m_lo, 0..]
+//     -> K_hi.Q_hi + K_lo.Q_hi + K_hi.Q_lo - m in two MFMAs (the SAFE path passes -m as the C operand instead);
 //   P.V (16 keys per MFMA): A rows 0-7 V_hi d, 8-15 V_lo d, 16 ones, 17-31 zeros (constant LDS rows); B = P_hi, then P_lo, into ONE
 //     accumulator: O[d] = row d + row 8+d is an in-lane add and row 16 is the softmax row sum (V_lo.P_lo rides along: 2^-22).
 // 52 MFMAs per head instead of 104, no cross-lane traffic between the score tile and the P.V operand.  SAFE as in softmax_pv.
@@ -598,7 +600,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 // both heads of the pair on the 32x32x16 core; a head's output (4 d per lane) goes through its own, by then dead,
                 // half of the wave's Q scratch into the pair-tile layout the fc operand wants (row 4g+r: head g >> 1, d = 4 (g & 1) + r)
                 const int hl = lane >> 5, n = lane & 31;
-                const _Float16* const crow = Vl + 8 * 16 * G::VS;         // [ones row][zeros row]
+                const _Float16* const crow = Vl + 8 * 16 * G::VS;         // [ones row][zeros row][{1, 1, 0..} row]
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int head = 2 * p + hh;
