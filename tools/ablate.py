@@ -2,7 +2,9 @@
 """Timing-only ablations of the decoder kernel (-DS2S_ABL=mask builds; outputs are garbage).
 f32 block: bit0 no softmax VALU, bit1 no LDS operand reads, bit2 no barriers, bit3 no K/V LDS stores, bit4 no LayerNorm.
 f16 block: 1 no exp, 2 no split, 4 no barriers, 32 no max/branch, 64 no row-sum MFMAs, 128 no FFN, 256 one key pass of four; unit loads L1-hot: 2048 K/V phase, 8192 attention phase, 16384 FFN.
-S2S_ABL_FLAGS adds extra -D flags (e.g. -DS2S_NO_FALLBACK so that garbage data cannot take the safe softmax path)."""
+S2S_ABL_FLAGS adds extra -D flags (e.g. -DS2S_NO_FALLBACK so that garbage data cannot take the safe softmax path).
+The decoder's attention core is softmax_pv32 (32x32x16 MFMA) since round 2: of the f16-block masks it honours 1, 2 (exp / split), 4,
+128 and the unit-load masks; 32, 64, 256, 512, 1024 belong to the 16x16x32 core (add -DS2S_ATT32=0 to S2S_ABL_FLAGS to ablate that one)."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
