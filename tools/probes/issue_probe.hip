@@ -104,6 +104,19 @@ int main() {
     run<1, 32, 4, 1, 0>("1 wave/SIMD: 4 mfma32 + 32 v_fma_mixlo interleaved", 256);
     run<1, 32, 0, 1, 0>("1 wave/SIMD: 4 mfma32 + 32 v_fma (again)", 256);
     run<1, 16, 4, 1, 0>("1 wave/SIMD: 4 mfma32 + 16 v_fma_mixlo interleaved", 256);
+    // sweep: vector instructions per MFMA, by kind (KIND 0 v_fma, 1 v_exp, 2 v_cvt_pk, 4 v_fma_mixlo), both MFMA shapes
+    run<1, 8, 4, 1, 0>("sweep 4 mfma32 +  8 mixlo", 256);
+    run<1, 24, 4, 1, 0>("sweep 4 mfma32 + 24 mixlo", 256);
+    run<1, 48, 4, 1, 0>("sweep 4 mfma32 + 48 mixlo", 256);
+    run<1, 64, 4, 1, 0>("sweep 4 mfma32 + 64 mixlo", 256);
+    run<1, 64, 1, 1, 0>("sweep 4 mfma32 + 64 v_exp", 256);
+    run<1, 64, 0, 1, 0>("sweep 4 mfma32 + 64 v_fma", 256);
+    run<1, 64, 2, 1, 0>("sweep 4 mfma32 + 64 v_cvt_pk", 256);
+    run<1, 64, 4, 0, 0>("sweep 8 mfma16 + 64 mixlo", 256);
+    run<1, 64, 1, 0, 0>("sweep 8 mfma16 + 64 v_exp", 256);
+    run<1, 64, 2, 0, 0>("sweep 8 mfma16 + 64 v_cvt_pk", 256);
+    run<0, 64, 4, 0, 0>("sweep 64 mixlo alone", 256);
+    run<0, 64, 1, 0, 0>("sweep 64 v_exp alone", 256);
     // two waves per SIMD (512 threads)
     run<1, 0, 0, 0, 0>("2 waves/SIMD: 8 mfma16 alone (each)", 512);
     run<0, 32, 0, 0, 0>("2 waves/SIMD: 32 v_fma alone (each)", 512);
