@@ -502,9 +502,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         f32x4 X[DEC_NQ][4];
         float sig_ext[DEC_NQ];
         {
+            int lg = lane;                 // (opaque, like lnf / ln: the gather's per-lane addresses are not kept across the group loop)
+            asm volatile("" : "+v"(lg));
             GatherRaw R;
-            dec_gather_issue(M, W, slot0, wave, lane, R);
-            dec_gather_finish(R, wave, lane, X, sig_ext);
+            dec_gather_issue(M, W, slot0, wave, lg, R);
+            dec_gather_finish(R, wave, lg, X, sig_ext);
         }
         DIAG_STAMP(8);
 #pragma unroll 1
