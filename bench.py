@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the predict hot path on MI355X (contract: see the task statement).
 
-A "step" is one pass of the hot path (s2s_predict_chunks: the fused frontend + decoder kernel, one
-launch per 32,768 chunks) over one batch of synthetic reads already resident in HBM.  Workload at N=1 (BASELINE.json configs[1]
+A "step" is one pass of the hot path (s2s_predict_chunks: the fused frontend + decoder kernel, ONE launch
+per step -- a launch takes up to 2^20 chunks) over one batch of synthetic reads already resident in HBM.  Workload at N=1 (BASELINE.json configs[1]
 shape): 1000 reads x 5000 nt = 312,000 chunks, default noise + duration samplers (noise_std 2.0,
 min_duration 3), synthetic k=9 checkpoint.  With N>1 every rank runs the same amount of work on
 its own read shard (weak scaling, no data-path collective); RCCL is used only for the barrier
@@ -84,13 +84,13 @@ def end_to_end(mode):
     fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
     out_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
-    def run(n_reads, ext="blow5"):
-        with tempfile.TemporaryDirectory(dir=out_dir) as td:
+    def run(n_reads, ext="blow5", where=out_dir, fasta=fasta, r=5000, c=-1):
+        with tempfile.TemporaryDirectory(dir=where) as td:
             out = os.path.join(td, "o." + ext)
             set_seeds(42)
             t0 = time.perf_counter()
             m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
-                              fasta=fasta, read_input=False, n=n_reads, r=5000, c=-1, out=out, profile="dna-r10-prom",
+                              fasta=fasta, read_input=False, n=n_reads, r=r, c=c, out=out, profile="dna-r10-prom",
                               dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
                               distr="expon", predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None,
                               bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
@@ -108,6 +108,28 @@ def end_to_end(mode):
     run(1000, "pod5")
     warm_p = [run(1000, "pod5") for _ in range(3)]
     elp, chunksp, sizep = sorted(warm_p)[1]
+    # the same configs[1] run onto the default temp directory (the box's real file system, not tmpfs)
+    disk_dir = tempfile.gettempdir()
+    disk = sorted(run(1000, where=None) for _ in range(3))[1]
+    # BASELINE.json configs[4] ("synthetic 100 Mb reference -c 30 -r 10000, pod5 out", 300,000 reads over 8 GPUs): ONE GPU's
+    # share -- a 12.5 Mb reference of 5 unequal contigs (rng 1234), -c 30 -r 10000 -> 37,500 reads ~ 23.6 M chunks ~ 5.7 GB of
+    # .pod5 -- written to the real file system when it has room (else tmpfs; else a stated fraction of the share)
+    import resource
+    import shutil
+    from seq2squiggle_amd.utils import write_synthetic_reference
+    need = 9 << 30
+    where5, frac5 = None, 1.0
+    if shutil.disk_usage(disk_dir).free < need:
+        where5 = out_dir
+        if out_dir is None or shutil.disk_usage(out_dir).free < need:
+            where5, frac5 = out_dir, 0.125
+    with tempfile.TemporaryDirectory(dir=out_dir) as td:
+        ref = os.path.join(td, "synthetic_ref.fasta")
+        total5 = write_synthetic_reference(ref, [int(L * frac5) for L in (4_000_000, 3_000_000, 2_500_000, 2_000_000, 1_000_000)])
+        rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        el5, chunks5, size5 = run(-1, "pod5", where=where5, fasta=ref, r=10000, c=30)
+        rss5 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    reads5 = round(30 * total5 / 10000)
     return {"workload": "example lambda genome -n 1000 -r 5000 -> .blow5 (zlib records), seed 42", "seconds": el,
             "warm_calls_seconds": [w[0] for w in warm], "pod5_warm_calls_seconds": [w[0] for w in warm_p],
             "first_call_seconds": first, "reads_per_sec": 1000 / el, "chunks": chunks, "chunks_per_sec": chunks / el,
@@ -118,6 +140,15 @@ def end_to_end(mode):
             "pod5": {"workload": "configs[1]'s reads -> .pod5 (VBZ signal rows: svb16 on the GPU, zstd on host threads), the "
                                  "container BASELINE configs[4] asks for", "seconds": elp, "reads_per_sec": 1000 / elp,
                      "chunks": chunksp, "chunks_per_sec": chunksp / elp, "output_bytes": sizep},
+            "real_file_system": {"workload": "configs[1] again, output on the default temp directory instead of tmpfs",
+                                 "output_dir": disk_dir, "seconds": disk[0], "chunks_per_sec": disk[1] / disk[0],
+                                 "reads_per_sec": 1000 / disk[0]},
+            "config5_share": {"workload": f"synthetic {total5 / 1e6:.3f} Mb reference (5 contigs, rng 1234) -c 30 -r 10000 -> .pod5 "
+                                          f"(VBZ rows): {frac5:g} of one GPU's share of BASELINE configs[4] (300,000 reads over 8 GPUs)",
+                              "fraction_of_one_gpu_share": frac5, "reads": reads5, "seconds": el5, "reads_per_sec": reads5 / el5,
+                              "chunks": chunks5, "chunks_per_sec": chunks5 / el5, "output_bytes": size5,
+                              "output_dir": where5 or disk_dir,
+                              "process_peak_rss_mb_before": rss0 / 1024.0, "process_peak_rss_mb_after": rss5 / 1024.0},
             "includes": "engine creation, read sampling, chunking, kernels, export, D2H, compression, file write"}
 
 

@@ -29,6 +29,7 @@ extern "C" {
 #define S2S_ERR_ARG (-1)     /* bad argument / unsupported configuration */
 #define S2S_ERR_HIP (-2)     /* a HIP runtime call failed                 */
 #define S2S_ERR_BLOB (-3)    /* weight blob has the wrong size            */
+#define S2S_ERR_CODEC (-4)   /* a host compression codec is unavailable (libzstd.so.1 not loadable) or failed */
 
 /* Decoder arithmetic.  F32 and F16X3 stay inside the 1e-4 pA MAE parity bound.
  *   S2S_MODE_F32    every product on the f32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32;
@@ -176,9 +177,12 @@ int s2s_export_reads(s2s_handle* h, void* stream, const float* signal, int32_t B
  *  variant       32: slow5 svb-zd blob = u32 n, (n+3)/4 control bytes (2 bits per value), data (zig-zag of 32-bit deltas);
  *               16: pod5 svb16 stream = (n+7)/8 control bytes (1 bit per value), data (zig-zag of 16-bit deltas): the
  *               input of the row's zstd frame;
- *  out           device bytes [capacity]; capacity >= N*4 + total_samples*3 + N (variant 32) or total_samples*2 + N + total/8
- *               (variant 16) always suffices;
- *  out_offsets   device [N+1] int64: blob i = out[out_offsets[i] : out_offsets[i+1]].
+ *  out           device bytes [capacity]; a row of n samples takes at most 4 + ceil(n/4) + 3n bytes (variant 32: a zig-zag
+ *               delta of two int16 samples can need 3 bytes) or ceil(n/8) + 2n (variant 16), so capacity >=
+ *               4N + 3 total + (total + 3N)/4 (variant 32) or 2 total + total/8 + N (variant 16) always suffices;
+ *  out_offsets   device [N+1] int64: blob i = out[out_offsets[i] : out_offsets[i+1]].  If the rows need more than
+ *               `capacity` bytes, the rows that do not fit are NOT written and out_offsets[N] comes back NEGATIVE
+ *               (minus the bytes needed): the caller must check it before framing the blobs.
  */
 int s2s_svb_encode(s2s_handle* h, void* stream, const int16_t* samples, const int64_t* read_offsets,
                    const int32_t* row_read, const int32_t* row_index, int32_t N, int64_t row_samples, int32_t variant,
@@ -213,6 +217,29 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
  * out_offs [n+1].  capacity >= s2s_blow5_pack_bound(total bytes, n) always suffices.  Returns the bytes written, or < 0. */
 int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n_rows, int32_t method, int32_t level,
                           int32_t threads, uint8_t* out, int64_t capacity, int64_t* out_offs);
+
+/* ---- host-side helper (no GPU work, no handle): replays the DRAWS of the reference's read sampler (utils.py:415-479
+ * `sampling`, with the read-length law of utils.py:325-331 `draw_expon_dis`) without building a read, so that a rank of a sharded
+ * run finds the generator state of its first read in microseconds per thousand reads instead of replaying them in the
+ * interpreter.  Per attempt the reference draws a start position (random.randint on the genome-wide coordinate), a strand
+ * (random.choice("+-"), DNA profiles only) and, for an accepted read, one random.choice("ACGT") per N in it; the length of
+ * attempt (read_i, retry) is scipy's expon law seeded with seed + read_i * (max_retries + 1) + retry, truncated and clipped to
+ * [1, total_len]; an attempt is rejected when a DNA read is cut short by its contig's end, is shorter than min_read_len or
+ * holds more than 10 % N (utils.py:381-400).
+ *
+ *  mt_state       in/out [625]: Python's random.getstate()[1] (624 Mersenne-Twister words + the index); on return the state
+ *                 in front of the first draw of read *out_next_read_i;
+ *  contig_ends    [n_contigs] running sum of the contig lengths (genome < 2^31 bases);
+ *  n_pos, n_pos_count   nullable [n_contigs]: per contig the sorted offsets of its N bases (NULL / 0 for a contig without N);
+ *  num_seqs, first_read_i   reads first_read_i .. num_seqs-1 are attempted in order;
+ *  stop_after     stop once this many reads have been accepted (< 0: never);
+ *  out_lengths    nullable [>= number of accepted reads]: their lengths.
+ * Returns the number of accepted reads, or < 0 (S2S_ERR_ARG: also when seed + num_seqs * (max_retries + 1) >= 2^32, where
+ * the reference's scipy seed would leave the range this fast path mirrors -- the caller then replays in Python). */
+int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32_t n_contigs,
+                           const int64_t* const* n_pos, const int64_t* n_pos_count, int64_t num_seqs, int64_t first_read_i, int64_t r,
+                           uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
+                           int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i);
 
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): 48 per-phase wave-cycle sums since the
  * last call (0-15 decoder, 16-31 unused, 32-47 the frontend's own

@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void s2s_svb_kernel(const short* __restrict__ 
     unsigned char* o = nullptr;
     if (WRITE) {
         const long long base = out_offs[row];
-        if (out_offs[row + 1] > capacity) return;            // (the host sized the buffer for the worst case: cannot happen)
+        if (out_offs[row + 1] > capacity) return;            // does not fit: skipped, and s2s_svb_check_kernel reports it
         o = out + base;
         if (VARIANT == 32 && tid == 0) { const unsigned nn = (unsigned)n; o[0] = nn; o[1] = nn >> 8; o[2] = nn >> 16; o[3] = nn >> 24; }
     }
@@ -697,6 +697,11 @@ __global__ __launch_bounds__(256) void s2s_svb_kernel(const short* __restrict__ 
         __syncthreads();
     }
     if (!WRITE && tid == 0) row_bytes[row] = (int)(hdr + nkeys + carry_s);
+}
+
+// s2s_svb_encode's overflow report: rows that do not fit are skipped by the WRITE pass; the total then comes back negative
+__global__ void s2s_svb_check_kernel(long long* __restrict__ out_offs, int n, long long capacity) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && out_offs[n] > capacity) out_offs[n] = -out_offs[n];
 }
 
 __global__ void s2s_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned c0, unsigned c1, unsigned c2, unsigned c3,
@@ -1272,6 +1277,7 @@ int s2s_svb_encode(s2s_handle* h, void* stream_, const int16_t* samples, const i
             hipLaunchKernelGGL((s2s_svb_kernel<16, true>), dim3(N), dim3(256), 0, stream, sp, ro, row_read, row_index,
                                (long long)row_samples, nullptr, oo, out, (long long)capacity);
     }
+    hipLaunchKernelGGL(s2s_svb_check_kernel, dim3(1), dim3(64), 0, stream, oo, N, (long long)capacity);
     HIP_TRY(h, hipGetLastError());
     return S2S_OK;
 }

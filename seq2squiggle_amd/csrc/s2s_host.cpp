@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -309,7 +310,7 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
     if (n < 0 || threads < 1 || (n > 0 && (!prefix || !prefix_offs || !suffix || !suffix_offs || !signal || !signal_offs || !out)))
         return S2S_ERR_ARG;
     if (method < 0 || method > 3) return S2S_ERR_ARG;
-    if (method == 2 && !zstd().ok) return S2S_ERR_ARG;
+    if (method == 2 && !zstd().ok) return S2S_ERR_CODEC;
     if (n == 0) return 0;
     std::lock_guard<std::mutex> guard(g_pool_mutex);
     if (!g_pool || g_pool->size() < threads) { delete g_pool; g_pool = new Pool(threads); }   // grows, never shrinks
@@ -388,7 +389,7 @@ int64_t s2s_blow5_pack(const uint8_t* prefix, const int64_t* prefix_offs, const 
     });
     for (void* d : defl)
         if (d) deflate().free_(d);
-    if (failed) return S2S_ERR_HIP;
+    if (failed) return S2S_ERR_CODEC;
 
     // where every record lands in `out`, then the copies (again on the workers: 10+ MB per batch)
     std::vector<int64_t> at(n + 1);
@@ -423,7 +424,7 @@ int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n, 
                           uint8_t* out, int64_t capacity, int64_t* out_offs) {
     if (n < 0 || threads < 1 || !out_offs || (n > 0 && (!in || !in_offs || !out))) return S2S_ERR_ARG;
     if (method != 1 && method != 2) return S2S_ERR_ARG;
-    if (method == 2 && !zstd().ok) return S2S_ERR_ARG;
+    if (method == 2 && !zstd().ok) return S2S_ERR_CODEC;
     out_offs[0] = 0;
     if (n == 0) return 0;
     std::lock_guard<std::mutex> guard(g_pool_mutex);
@@ -461,7 +462,7 @@ int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n, 
     });
     for (void* d : defl)
         if (d) deflate().free_(d);
-    if (failed) return S2S_ERR_HIP;
+    if (failed) return S2S_ERR_CODEC;
     int64_t pos = 0;
     for (int i = 0; i < n; ++i) {                               // close the gaps, in row order
         if (pos != slot[i]) std::memmove(out + pos, out + slot[i], size[i]);
@@ -472,3 +473,126 @@ int64_t s2s_compress_rows(const uint8_t* in, const int64_t* in_offs, int32_t n, 
 }
 
 }  // extern "C"
+
+// ================================================================================ read-sampler replay
+// The reference samples reads one after the other from Python's global `random` (Mersenne Twister): per attempt a start
+// position (random.randint), a strand (random.choice, DNA only), and per N of an accepted read a replacement base; the read
+// length comes from scipy with a per-(read, retry) seed (utils.py:311-331, 415-479).  Every draw consumes a data-dependent
+// number of generator words, so a rank that owns reads lo..hi of a sharded run can only find the generator state of read lo by
+// replaying the draws of reads 0..lo-1 -- 4.3 us per read in the interpreter, a few tens of ns here.  Nothing is built: the
+// function walks the draws, returns the accepted reads' lengths and leaves the generator where the next read starts.
+namespace {
+
+struct Mt19937 {                      // CPython's _randommodule.c generator: state = random.getstate()[1] (624 words + index)
+    uint32_t* mt;
+    uint32_t idx;
+    uint32_t next() {
+        if (idx >= 624) {
+            int kk;
+            for (kk = 0; kk < 624 - 397; ++kk) {
+                const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+                mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            for (; kk < 623; ++kk) {
+                const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+                mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    // random._randbelow_with_getrandbits(n), 0 < n < 2^32: k = n.bit_length(); redraw getrandbits(k) until < n
+    uint64_t below(uint64_t n) {
+        int k = 0;
+        for (uint64_t t = n; t; t >>= 1) ++k;
+        for (;;) {
+            const uint64_t r = (uint64_t)(next() >> (32 - k));
+            if (r < n) return r;
+        }
+    }
+};
+
+inline uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// draw_expon_dis(mean = r, seed): scipy's expon.rvs(loc, scale, size = 1, random_state = seed) builds np.random.RandomState(seed)
+// (init_genrand) and takes loc + scale * -log(1 - random_sample()); then int(x * r / 7106), clipped to [1, total_len]
+// (reference utils.py:325-331).  Only the generator's first two outputs are needed: state words 0-2, 397, 398.
+#pragma clang fp contract(off)
+int64_t expon_length(uint32_t seed, double r, int64_t total_len) {
+    uint32_t x = seed, w0 = seed, w1 = 0, w2 = 0, w397 = 0, w398 = 0;
+    for (uint32_t i = 1; i < 399; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + i;
+        if (i == 1) w1 = x; else if (i == 2) w2 = x; else if (i == 397) w397 = x; else if (i == 398) w398 = x;
+    }
+    auto twist = [](uint32_t a, uint32_t b, uint32_t c) {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    const uint32_t a = mt_temper(twist(w0, w1, w397)) >> 5, b = mt_temper(twist(w1, w2, w398)) >> 6;
+    const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    const double e = -std::log(1.0 - u);
+    const double loc = 213.98910256668592, scale = 6972.5319847131141, fitted_mean = 7106.0;
+    double v = scale * e;
+    v = loc + v;
+    v = v * r;
+    v = v / fitted_mean;
+    int64_t n = (int64_t)v;                                  // numpy .astype(int): truncation
+    if (n < 1) n = 1;
+    if (n > total_len) n = total_len;
+    return n;
+}
+
+}  // namespace
+
+extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32_t n_contigs,
+                                      const int64_t* const* n_pos, const int64_t* n_pos_count, int64_t num_seqs, int64_t first_read_i, int64_t r,
+                                      uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
+                                      int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i) {
+    if (!mt_state || !contig_ends || n_contigs < 1 || num_seqs < 0 || first_read_i < 0 || r <= 0 || max_retries < 1 || !out_next_read_i)
+        return S2S_ERR_ARG;
+    const int64_t genome = contig_ends[n_contigs - 1];
+    if (genome < 1 || genome >= (1ll << 31) || mt_state[624] > 624) return S2S_ERR_ARG;
+    if (seed + (uint64_t)num_seqs * (uint64_t)(max_retries + 1) >= (1ull << 32)) return S2S_ERR_ARG;   // (the scipy seed must not wrap)
+    Mt19937 g{mt_state, mt_state[624]};
+    int64_t accepted = 0, read_i = first_read_i;
+    for (; read_i < num_seqs && (stop_after < 0 || accepted < stop_after); ++read_i) {
+        for (int retry = 0; retry < max_retries; ++retry) {
+            const int64_t pos = (int64_t)g.below((uint64_t)genome);                 // random.randint(0, total_genome_len - 1)
+            const int64_t* ce = std::upper_bound(contig_ends, contig_ends + n_contigs, pos);   // bisect_right
+            const int where = (int)(ce - contig_ends);
+            const int64_t start = where ? contig_ends[where - 1] : 0, offset = pos - start, clen = contig_ends[where] - start;
+            const int64_t length = expon_length((uint32_t)(seed + (uint64_t)read_i * (uint64_t)(max_retries + 1) + (uint64_t)retry),
+                                                (double)r, total_len);
+            const int64_t got = std::min(length, clen - offset);                     // genome[offset : offset + length]
+            if (is_dna) (void)g.below(2);                                           // random.choice("+-")
+            if (is_dna && got != length) continue;                                  // read_check: end-of-contig rejection
+            if (got < min_read_len) continue;
+            int64_t n_count = 0;
+            if (n_pos && n_pos[where]) {                                            // read.count("N"): sorted N positions of the contig
+                const int64_t* p0 = n_pos[where], *p1 = p0 + n_pos_count[where];
+                n_count = std::lower_bound(p0, p1, offset + got) - std::lower_bound(p0, p1, offset);
+                if ((double)n_count > 0.1 * (double)length) continue;
+            }
+            for (int64_t i = 0; i < n_count; ++i) (void)g.below(4);                 // fill_unknown_bases: one choice("ACGT") per N
+            if (out_lengths) out_lengths[accepted] = (int32_t)got;
+            ++accepted;
+            break;
+        }
+    }
+    mt_state[624] = g.idx;
+    *out_next_read_i = read_i;
+    return accepted;
+}

@@ -184,15 +184,16 @@ class Engine:
     @staticmethod
     def svb_capacity(total_samples_bound: int, n_rows: int, variant: int) -> int:
         """Bytes s2s_svb_encode may write for n_rows rows holding at most total_samples_bound samples together."""
-        if variant == 32:
-            return 3 * total_samples_bound + 5 * n_rows
+        if variant == 32:      # per row: u32 count + ceil(n/4) control bytes + up to 3 bytes per zig-zag delta of int16 samples
+            return 4 * n_rows + 3 * total_samples_bound + (total_samples_bound + 3 * n_rows) // 4
         return 2 * total_samples_bound + total_samples_bound // 8 + n_rows
 
     def svb_encode(self, dac: torch.Tensor, read_offsets: torch.Tensor, row_read: torch.Tensor, row_index: torch.Tensor,
                    row_samples: int, variant: int, total_samples_bound: int, out: torch.Tensor = None,
                    out_offsets: torch.Tensor = None):
         """StreamVByte blobs of the rows (see s2s_svb_encode in include/s2s_hip.h) -> dict(out uint8 [capacity],
-        offsets int64 [N+1]) on the device.  total_samples_bound: an upper bound of the samples the rows hold together.
+        offsets int64 [N+1]) on the device; offsets[N] < 0 reports a too-small `out` (minus the bytes needed; rows that did
+        not fit are unwritten).  total_samples_bound: an upper bound of the samples the rows hold together.
         out / out_offsets: write there (uint8 [>= svb_capacity(...)] / int64 [N+1]) instead of into fresh tensors."""
         N = int(row_read.shape[0])
         for name, t, dt in (("dac", dac, torch.int16), ("read_offsets", read_offsets, torch.int64),

@@ -286,6 +286,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         if gpu_rows:
             N = int(row_read.shape[0])
             row_offs = host[8 * (R + 1): 8 * (R + 1) + 8 * (N + 1)].view(np.int64)
+            if row_offs[-1] < 0:               # s2s_svb_encode: the coded rows did not fit (cannot happen with svb_capacity's bound)
+                raise RuntimeError(f"s2s_svb_encode needed {-int(row_offs[-1])} bytes, the buffer holds {host.size - head}")
             recs = writer.svb_records(ids, offs, row_read, row_offs, host[head: head + int(row_offs[-1])])
         else:
             recs = writer.dac_records(ids, host[head: head + 2 * int(offs[-1])].view(np.int16), offs)
@@ -370,17 +372,20 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
             def shard_of(lens):
                 lo, hi, picked["first"] = shard_reads(lens, config["seq_kmer"], world)[rank]
                 picked["lo"] = lo
+                picked["records_before"] = sum(1 for L in lens[:lo] if _n_chunks(int(L), config["seq_kmer"]) > 0)
                 return lo, hi
             reads, lens = sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of)
-            first_chunk, first_read = picked["first"], picked["lo"]
+            first_chunk, first_read = picked["first"], picked["records_before"]
             logger.info(f"rank {rank}/{world}: reads {picked['lo']}.. of {len(lens)}, first global chunk {first_chunk}")
         else:
             reads, total_l = get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read_len, lazy=world == 1)
             if world > 1:                  # read mode: every rank parses the same file, then keeps its contiguous share
                 reads = list(reads)
                 lo, hi, first_chunk = shard_reads([len(s) for s, _ in reads], config["seq_kmer"], world)[rank]
+                # records written before this shard: reads too short for one chunk produce none (dataloader.py:393-398), so they
+                # must not advance the shard writer's read numbering / record draws either
+                first_read = sum(1 for s_, _ in reads[:lo] if _n_chunks(len(s_), config["seq_kmer"]) > 0)
                 reads = reads[lo:hi]
-                first_read = lo
                 logger.info(f"rank {rank}/{world}: reads {lo}..{hi}, first global chunk {first_chunk}")
     finally:
         if _TRACE is not None:

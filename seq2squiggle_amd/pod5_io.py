@@ -175,8 +175,15 @@ def _signal_batch(pa, schema, rows, vbz=True):
     ids = pa.array([r[0] for r in rows], pa.binary(16))
     if vbz:
         from .codecs import vbz_compress
-        blobs = [r[2] if r[2] is not None else vbz_compress(r[1]) for r in rows]
-        return pa.record_batch([ids, pa.array(blobs, pa.large_binary()), pa.array(counts, pa.uint32())], schema=schema)
+        # the column is assembled from ONE data buffer + offsets.  (pa.array(list of memoryviews) must not be used here: pyarrow
+        # 25 leaks a memoryview per item, each of which pins the whole compressed batch it is a slice of -- the writer's memory
+        # then grows by the size of the output, 7 GB for one GPU's share of BASELINE configs[4].)
+        blobs = [np.frombuffer(r[2] if r[2] is not None else vbz_compress(r[1]), dtype=np.uint8) for r in rows]
+        offs = np.zeros(len(blobs) + 1, np.int64)
+        np.cumsum([b.size for b in blobs], out=offs[1:])
+        data = np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)
+        col = pa.LargeBinaryArray.from_buffers(pa.large_binary(), len(blobs), [None, pa.py_buffer(offs), pa.py_buffer(data)])
+        return pa.record_batch([ids, col, pa.array(counts, pa.uint32())], schema=schema)
     flat = np.concatenate([r[1] for r in rows]) if rows else np.zeros(0, np.int16)
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     return pa.record_batch([ids, pa.LargeListArray.from_arrays(pa.array(offs, pa.int64()), pa.array(flat, pa.int16())),
@@ -389,3 +396,53 @@ def read_pod5(path: str) -> dict:
         reads.append(row)
     return {"footer": footer, "schema_metadata": {k.decode(): v.decode() for k, v in reads_t.schema.metadata.items()},
             "run_info": run_t.to_pylist(), "reads": reads, "signal_rows": sig.num_rows}
+
+
+def iter_pod5(path: str):
+    """read_pod5() for files that do not fit in memory: the file is memory-mapped, the reads table (about 100 B per read) is read
+    whole, and the signal table is walked one record batch (SIGNAL_BATCH_ROWS rows) at a time -- yields (row dict without
+    `signal`, int16 samples) per read in file order; same container checks as read_pod5."""
+    pa = _pa()
+    src = pa.memory_map(path, "r")
+    buf = src.read_buffer()
+    size = buf.size
+    head, tail = buf.slice(0, 24).to_pybytes(), buf.slice(size - 32, 32).to_pybytes()
+    if head[:8] != SIGNATURE or tail[-8:] != SIGNATURE:
+        raise ValueError("not a POD5 file: bad signature")
+    marker = head[8:24]
+    if tail[8:24] != marker:
+        raise ValueError("section markers differ")
+    flen = struct.unpack_from("<q", tail, 0)[0]
+    fstart = size - 32 - flen
+    if buf.slice(fstart - 8, 8).to_pybytes() != FOOTER_MAGIC:
+        raise ValueError("footer magic not found")
+    footer = parse_footer(buf.slice(fstart, flen).to_pybytes())
+    files = {}
+    for e in footer["contents"]:
+        end = e["offset"] + e["length"]
+        if buf.slice(end + (-e["length"] % 8), 16).to_pybytes() != marker:
+            raise ValueError("embedded file is not followed by the section marker")
+        files[e["content_type"]] = pa.ipc.open_file(pa.BufferReader(buf.slice(e["offset"], e["length"])))
+    sig = files[CT_SIGNAL]
+    vbz = pa.types.is_large_binary(sig.schema.field("signal").type.storage_type
+                                   if isinstance(sig.schema.field("signal").type, pa.ExtensionType) else sig.schema.field("signal").type)
+    cache = {"i": -1}
+
+    def row(i):
+        b, j = divmod(i, SIGNAL_BATCH_ROWS)
+        if cache["i"] != b:
+            rb = sig.get_batch(b)
+            col = rb.column(rb.schema.get_field_index("signal"))
+            if isinstance(col, pa.ExtensionArray):
+                col = col.storage
+            cache.update(i=b, col=col, counts=rb.column(rb.schema.get_field_index("samples")).to_numpy())
+        col, n = cache["col"], int(cache["counts"][j])
+        if vbz:
+            from .codecs import vbz_decompress
+            return vbz_decompress(col[j].as_buffer(), n)
+        return np.asarray(col[j].values.to_numpy(zero_copy_only=False), dtype=np.int16)
+    reads_t = files[CT_READS]
+    for b in range(reads_t.num_record_batches):
+        for r in reads_t.get_batch(b).to_pylist():
+            raw = np.concatenate([row(i) for i in r["signal"]]) if r["signal"] else np.zeros(0, np.int16)
+            yield dict(r, read_id=uuid.UUID(bytes=r["read_id"])), raw

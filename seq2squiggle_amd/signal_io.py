@@ -137,11 +137,18 @@ class BLOW5Writer:
         self.deflate = "huffman"
         self.threads = cpu_share()            # compression threads (the reference: cpu_count)
         self._out = None                      # packed records of the batch being written
+        self._warned_fallback = False
+        if self.signal_compression == "svb-zd":
+            logger.warning("BLOW5 signal compression svb-zd is EXPERIMENTAL here: the codec is pinned by known-answer vectors, "
+                           "but how slow5lib frames the blob inside a record could not be checked against the library; files "
+                           "written this way may not open in slow5tools. The default (zlib records, raw int16 signal) is safe.")
 
     def start_at(self, read_index: int) -> None:
-        """Rank shards (parallel.py): this writer's first read is read `read_index` of the whole job, so read ids and
-        read_number continue from there and the record draws continue the single-process np.random stream (exact as long
-        as no earlier read came out empty).  start_time stays per file."""
+        """Rank shards (parallel.py): `read_index` records precede this writer's first one in the whole job (inference_run counts
+        the reads of earlier shards that have at least one chunk), so read ids and read_number continue from there and the
+        record draws continue the single-process np.random stream.  One caveat remains: a read whose signal strips to nothing
+        (every sample exactly 0) writes no record, which a later shard cannot know -- ids stay unique, but from there on they
+        differ from the single-process numbering.  start_time stays per file."""
         if self.n_written:
             raise RuntimeError("start_at() must come before the first record")
         self.n_written = int(read_index)
@@ -353,20 +360,35 @@ class BLOW5Writer:
             # (the reference: write_record_batch(threads=cpu_count), signal_io.py:167-171)
             recs = recs if isinstance(recs, list) else list(recs)
             if recs:
-                f.write(self._pack_native(recs))
+                try:
+                    packed = self._pack_native(recs)
+                except (RuntimeError, OSError) as e:          # library not loadable / codec missing: same bytes layout, in Python
+                    if not self._warned_fallback:
+                        logger.warning(f"native BLOW5 record packer unavailable ({e}); compressing records in Python")
+                        self._warned_fallback = True
+                    packed = b"".join(map(self._blow5_record, recs))
+                f.write(packed)
             f.write(self._EOF)
 
 
 def read_blow5(path):
-    """Minimal reader of the files written above (tests / round-trip only)."""
+    """Minimal reader of the files written above (tests / round-trip only): -> (header text, list of records)."""
+    it = iter_blow5(path)
+    header = next(it)
+    return header, list(it)
+
+
+def iter_blow5(path):
+    """read_blow5() with bounded memory (the file is memory-mapped): yields the header text, then one record at a time."""
+    import mmap
     from . import codecs
     with open(path, "rb") as f:
-        data = f.read()
+        data = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
     assert data[:6] == b"BLOW5\x01" and data[-5:] == BLOW5Writer._EOF
     rec_m, sig_m = data[9], data[14]
     hlen = struct.unpack_from("<I", data, 64)[0]
-    header = data[68:68 + hlen].decode()
-    pos, recs = 68 + hlen, []
+    yield data[68:68 + hlen].decode()
+    pos = 68 + hlen
     while pos < len(data) - 5:
         n = struct.unpack_from("<Q", data, pos)[0]
         body = data[pos + 8:pos + 8 + n]
@@ -389,10 +411,9 @@ def read_blow5(path):
         (cl,) = struct.unpack_from("<H", body, o); o += 2
         ch = body[o:o + cl].decode(); o += cl
         mb, rn, mux, st_ = struct.unpack_from("<diBQ", body, o)
-        recs.append({"read_id": rid, "read_group": rg, "digitisation": dig, "offset": off, "range": rng,
-                     "sampling_rate": sr, "len_raw_signal": nsig, "signal": sig, "channel_number": ch,
-                     "median_before": mb, "read_number": rn, "start_mux": mux, "start_time": st_})
-    return header, recs
+        yield {"read_id": rid, "read_group": rg, "digitisation": dig, "offset": off, "range": rng,
+               "sampling_rate": sr, "len_raw_signal": nsig, "signal": sig, "channel_number": ch,
+               "median_before": mb, "read_number": rn, "start_mux": mux, "start_time": st_}
 
 
 def read_slow5(path):
@@ -558,8 +579,12 @@ class POD5Writer:
         got = L.s2s_compress_rows(src, offs.ctypes.data, len(rows), 2, 1, cpu_share(),
                                   out.ctypes.data, cap, out_offs.ctypes.data)
         del keep
-        if got < 0:
-            raise RuntimeError(f"s2s_compress_rows failed ({got})")
+        if got < 0:                                   # S2S_ERR_CODEC: libzstd.so.1 not loadable -> the pyarrow / ctypes codec of codecs.py
+            from .codecs import zstd_compress
+            logger.warning(f"s2s_compress_rows failed ({got}); compressing signal rows in Python")
+            blobs = [zstd_compress(bytes(b), 1) for b, _ in rows]
+            np.cumsum([len(b) for b in blobs], out=out_offs[1:])
+            out = np.frombuffer(b"".join(blobs), dtype=np.uint8)
         view = memoryview(out)
         i = 0
         for r in recs:

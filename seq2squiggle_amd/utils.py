@@ -207,8 +207,49 @@ def sampling(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, prof
                               materialise))
 
 
+def replay_sampler(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20,
+                   first_read_i=0, stop_after=-1, want_lengths=True, _cache=None):
+    """The draws of sampling_iter() for reads first_read_i.. without building a read, in native code (s2s_sampler_replay in
+    libs2s_hip.so, host only): advances the global `random` generator exactly as sampling_iter would and returns
+    (lengths of the accepted reads | None, index of the next read to attempt) -- or None when the native path does not
+    apply (another length law, a seed outside the scipy fast range, a genome of 2 Gb or more, library not loadable): the
+    caller then replays in Python.  stop_after: stop once that many reads have been accepted."""
+    import ctypes as C
+    genome_total = sum(genome_lens)
+    if distr != "expon" or r <= 0 or not (0 <= seed and seed + num_seqs * (max_retries + 1) < 2 ** 32) or genome_total >= 2 ** 31:
+        return None
+    try:
+        from ._lib import lib
+        L = lib()
+    except (RuntimeError, OSError):
+        return None
+    version, internal, gauss = random.getstate()
+    if version != 3 or len(internal) != 625:
+        return None
+    state = np.array(internal, dtype=np.uint32)
+    ends = np.array(list(itertools.accumulate(genome_lens)), dtype=np.int64)
+    cache = _cache if _cache is not None else {}
+    if "n_pos" not in cache:                       # per contig: the sorted offsets of its N bases (empty for most contigs)
+        cache["n_pos"] = [np.flatnonzero(np.frombuffer(g_.encode("latin-1"), np.uint8) == ord("N")).astype(np.int64)
+                          if "N" in g_ else None for g_ in genome_seqs]
+    n_pos = cache["n_pos"]
+    ptrs = (C.c_void_p * len(n_pos))(*[None if p_ is None else p_.ctypes.data for p_ in n_pos])
+    counts = np.array([0 if p_ is None else p_.size for p_ in n_pos], dtype=np.int64)
+    n_left = max(num_seqs - first_read_i, 0)
+    out = np.empty(n_left if stop_after < 0 else min(n_left, stop_after), np.int32) if want_lengths else None
+    nxt = C.c_int64(0)
+    got = L.s2s_sampler_replay(state.ctypes.data, ends.ctypes.data, len(ends), C.cast(ptrs, C.c_void_p), counts.ctypes.data, int(num_seqs),
+                               int(first_read_i), int(r), int(seed), int(total_len), int(profile.startswith("dna")),
+                               int(min_read_len), int(max_retries), int(stop_after), None if out is None else out.ctypes.data,
+                               C.byref(nxt))
+    if got < 0:
+        return None
+    random.setstate((3, tuple(int(x) for x in state), gauss))
+    return (out[:got] if out is not None else None), int(nxt.value)
+
+
 def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len=30, max_retries=20,
-                  materialise=None):
+                  materialise=None, first_read_i=0, n_accepted=0):
     """Sample reads from the reference (utils.py:415-479), one at a time: the predict loop pulls reads as it packs batches,
     so the GPU starts after the first batch's worth of draws instead of after all of them.  The order of draws from the global `random`
     stream (start position, strand, N replacement) and the per-(read, retry) scipy seed
@@ -217,8 +258,10 @@ def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr,
 
     materialise = (lo, hi): only the accepted reads lo..hi-1 are built as strings, the others are returned as their
     LENGTH (an int) -- every draw is still made, so the stream and the read set are unchanged; a rank of a sharded run
-    pays the string work (slice copy, reverse complement) only for its own reads."""
-    n_accepted = 0
+    pays the string work (slice copy, reverse complement) only for its own reads.
+
+    first_read_i / n_accepted: continue a run whose earlier reads were consumed elsewhere (replay_sampler): the global
+    `random` state must be the one in front of read first_read_i, n_accepted the number of reads accepted before it."""
     total_genome_len = sum(genome_lens)
     # the first-try lengths of a block of reads in one vectorised pass (the per-seed scipy call costs ~100 us and is what
     # the reference's sampler spends its time in); retries and the other distributions go through scipy one by one
@@ -255,7 +298,7 @@ def sampling_iter(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr,
             return None
         return (fill_unknown_bases(read) if contig_has_n[where] and "N" in read else read), strand
 
-    for read_i in range(num_seqs):
+    for read_i in range(first_read_i, num_seqs):
         for retry in range(max_retries):
             got = attempt(read_i, retry)
             if got is None:
@@ -319,20 +362,34 @@ def _check_sampling_args(n, r, c):
 
 def sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of):
     """One rank's share of the read set sample_reads_from_reference would draw: pass 1 replays the sampler for the read
-    LENGTHS only, `shard_of(lengths)` -> (lo, hi) picks the rank's contiguous range, pass 2 replays it from the same
-    `random` state, builds the strings of that range only and stops behind it.  Pass 2 is lazy: the predict loop pulls the
-    rank's reads while it packs batches.  -> (iterator over reads lo..hi-1 as (seq, uuid) pairs, all read lengths)."""
+    LENGTHS only, `shard_of(lengths)` -> (lo, hi) picks the rank's contiguous range, pass 2 moves the `random` generator in
+    front of read lo, then the rank's reads are built lazily (the predict loop pulls them while it packs batches) and the
+    iterator stops behind read hi-1.  Both replays run in native code when the reference's default length law is in use
+    (replay_sampler: ~25 ns per read instead of 4.3 us -- 300,000 reads of BASELINE configs[4]: 15 ms instead of 1.3 s per pass,
+    which every rank pays before its first kernel); otherwise in the interpreter, draw for draw.
+    -> (iterator over reads lo..hi-1 as (seq, uuid) pairs, all read lengths)."""
     _check_sampling_args(n, r, c)
     total_len = sum(len(seq) for seq in genome_seqs)
     seq_num = n if n != -1 else round(c * total_len / r)
     state = random.getstate()
-    lens = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(0, 0))
+    cache = {}
+    fast = replay_sampler(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, _cache=cache)
+    if fast is not None:
+        lens = fast[0].tolist()
+    else:
+        lens = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(0, 0))
     lo, hi = shard_of(lens)
     random.setstate(state)
+    start_i, start_acc = 0, 0
+    if fast is not None and lo > 0:
+        skipped = replay_sampler(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
+                                 stop_after=lo, want_lengths=False, _cache=cache)
+        start_i, start_acc = skipped[1], lo
 
     def own_reads():
-        for i, rd in enumerate(sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
-                                             materialise=(lo, hi))):
+        it = sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
+                           materialise=(lo, hi), first_read_i=start_i, n_accepted=start_acc)
+        for i, rd in enumerate(it, start=start_acc):
             if i >= hi:
                 return
             if i >= lo:
@@ -399,6 +456,30 @@ def get_reads(fasta, read_input, n, r, c, config, distr, seed, profile, min_read
 
 
 # --------------------------------------------------------------------------------------- seeds / logging
+def write_synthetic_reference(path, contig_lens, seed=1234, n_runs=True):
+    """The synthetic reference of BASELINE.json configs[4] at any size (tests, bench.py): i.i.d. ACGT from numpy
+    default_rng(seed), one contig per entry of contig_lens, 80 columns, optionally a short run of N per contig (the
+    N -> random base path of the sampler, reference utils.py:402-403).  Returns the total length."""
+    _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    with open(path, "wb") as f:
+        for i, L in enumerate(contig_lens):
+            seq = _ACGT[rng.integers(0, 4, L)]
+            if n_runs:
+                seq[1000:1010] = ord("N")
+            f.write(f">contig{i}\n".encode())
+            rows = -(-L // 80)
+            body = np.full((rows, 81), ord("\n"), np.uint8)
+            padded = np.zeros(rows * 80, np.uint8)
+            padded[:L] = seq
+            body[:, :80] = padded.reshape(rows, 80)
+            lines = body.reshape(-1)
+            if L % 80:                                              # drop the padding of the last line, keep its newline
+                lines = np.concatenate([lines[: (L // 80) * 81 + L % 80], np.array([ord("\n")], np.uint8)])
+            f.write(lines.tobytes())
+    return sum(contig_lens)
+
+
 def set_seeds(seed: int) -> int:
     """utils.py:722-741: seed 0 draws a fresh one; seeds python, numpy and torch.  Returns the seed used
     (it also keys the device-side Philox generator)."""

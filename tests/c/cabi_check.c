@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
     const char* names[] = {"s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
                            "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read",
-                           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows"};
+                           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay"};
     for (unsigned i = 0; i < sizeof names / sizeof *names; ++i)
         if (!dlsym(lib, names[i])) { fprintf(stderr, "missing symbol %s\n", names[i]); return 4; }
     blob_floats_fn blob_floats = (blob_floats_fn)dlsym(lib, "s2s_blob_floats");
@@ -49,6 +49,21 @@ int main(int argc, char** argv) {
     const uint8_t want[] = {4, 0, 0, 0, 0, 0, 0, 0, 'A', 1, 2, 'x', 7, 0, 0, 0, 0, 0, 0, 0, 'B', 3, 4, 5, 6, 'y', 'z'};
     if (got != (int64_t)sizeof want || memcmp(out, want, sizeof want)) return 12;
     if (pack(head, head_offs, tail, tail_offs, sig, sig_offs, 2, 0, 1, 3, out, 8) >= 0) return 13;   /* too small a buffer */
+    /* the read-sampler replay from plain C: a generator state of init_genrand(5489) (the Mersenne Twister's reference seed, index
+     * 624), one 1000-base contig without N, five reads of mean length 100: all accepted on some retry, state advanced */
+    typedef int64_t (*replay_fn)(uint32_t*, const int64_t*, int32_t, const int64_t* const*, const int64_t*, int64_t, int64_t, int64_t,
+                                 uint64_t, int64_t, int32_t, int32_t, int32_t, int64_t, int32_t*, int64_t*);
+    replay_fn replay = (replay_fn)dlsym(lib, "s2s_sampler_replay");
+    uint32_t mt[625];
+    mt[0] = 5489u;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    mt[624] = 624;
+    const int64_t ends[] = {1000};
+    int32_t lens[5];
+    int64_t next_i = -1;
+    if (replay(mt, ends, 1, 0, 0, 5, 0, 100, 42, 1000, 1, 30, 20, -1, lens, &next_i) != 5 || next_i != 5 || mt[624] >= 624) return 14;
+    for (int i = 0; i < 5; ++i) if (lens[i] < 30 || lens[i] > 1000) return 15;
+    if (replay(mt, ends, 1, 0, 0, 5, 0, 0, 42, 1000, 1, 30, 20, -1, lens, &next_i) != S2S_ERR_ARG) return 16;   /* r must be > 0 */
     printf("CABI_OK %zu\n", n);
     return 0;
 }

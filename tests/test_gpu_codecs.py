@@ -137,3 +137,47 @@ def test_outputs_into_one_caller_buffer(eng):
         eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, out_dac=buf2[48:1000].view(torch.int16))
     with pytest.raises(ValueError):
         eng.svb_encode(ex["dac"], ex["offsets"], rr, ri, 1 << 40, 32, B * 250, out=buf[head: head + 100])
+
+
+def test_worst_case_rows_fill_the_stated_capacity_and_overflow_is_reported(eng):
+    """Alternating -32768 / 32767 samples: every zig-zag delta of the 32-bit variant needs 3 bytes, so a row of n samples takes
+    4 + ceil(n/4) + 3n bytes -- exactly the bound include/s2s_hip.h states (round 2's bound forgot the control bytes).  The blobs
+    must fit Engine.svb_capacity, equal the numpy codec, and a buffer that is too small must come back with a NEGATIVE total
+    (minus the bytes needed) instead of silently skipped rows."""
+    lens = [1, 4, 5, 4099, 70001]
+    reads = []
+    for n in lens:
+        x = np.where(np.arange(n) % 2 == 0, -32768, 32767).astype(np.int16)
+        reads.append(x)
+    flat = np.concatenate(reads)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    R, total = len(lens), int(offs[-1])
+    args = (torch.from_numpy(flat).cuda(), torch.from_numpy(offs).cuda(), torch.arange(R, dtype=torch.int32).cuda(),
+            torch.zeros(R, dtype=torch.int32).cuda(), 1 << 40, 32, total)
+    r = eng.svb_encode(*args)
+    o, out = r["offsets"].cpu().numpy(), r["out"].cpu().numpy()
+    need = sum(4 + -(-n // 4) + 3 * n - 1 for n in lens)          # (only a row's first delta, against 0, takes 2 bytes: -32768 -> 65535)
+    assert o[-1] == need <= eng.svb_capacity(total, R, 32)
+    assert eng.svb_capacity(total, R, 32) - need < 4 * R + 8                        # the bound is tight
+    for i, x in enumerate(reads):
+        assert out[o[i]:o[i + 1]].tobytes() == C.svb_zd_compress(x), i
+    # 16-bit variant on the same data: 2 bytes per value
+    r16 = eng.svb_encode(*args[:4], 1 << 40, 16, total)
+    o16 = r16["offsets"].cpu().numpy()
+    assert o16[-1] <= eng.svb_capacity(total, R, 16)
+    # a too-small buffer: flagged, rows that fit are still exact
+    small = torch.zeros(need - 1000, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        eng.svb_encode(*args, out=small)                                            # the engine refuses views below its bound ...
+    L = S._lib.lib()
+    import ctypes as Ct
+    offs_d = torch.zeros(R + 1, dtype=torch.int64, device="cuda")
+    rc = L.s2s_svb_encode(eng._h, None, Ct.c_void_p(args[0].data_ptr()), Ct.c_void_p(args[1].data_ptr()), Ct.c_void_p(args[2].data_ptr()),
+                          Ct.c_void_p(args[3].data_ptr()), R, 1 << 40, 32, Ct.c_void_p(small.data_ptr()), small.numel(),
+                          Ct.c_void_p(offs_d.data_ptr()))                           # ... the C ABI reports it
+    torch.cuda.synchronize()
+    assert rc == 0 and int(offs_d[-1]) == -need
+    got = small.cpu().numpy()
+    oo = offs_d.cpu().numpy()
+    for i in range(R - 1):                                                          # every row but the last fits
+        assert got[oo[i]:oo[i + 1]].tobytes() == C.svb_zd_compress(reads[i]), i

@@ -8,6 +8,8 @@ quantity checked is size-independent.
 configs[3] ("dna_r9_min profile -n 100000 -r 8000 --noise-std 1.5"): the k = 6 chemistry at its full per-GPU size class
 (>= 300 k chunks in one call) with the properties test_full_size_properties checks for k = 9, plus the CLI-level flow."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -22,6 +24,10 @@ from conftest import GOLDEN, load_ckpt
 
 pytestmark = pytest.mark.gpu
 LUT = np.frombuffer(b"ACGT", dtype=np.uint8)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+write_synthetic_reference = U.write_synthetic_reference
 
 
 def _run(out, fasta, profile, ckpt, *, n=-1, r=1000, c=-1, noise_std=2.0, seed=42, streaming=True, read_input=False):
@@ -148,3 +154,90 @@ def test_config4_cli_flow_k6(tmp_path):
     for x, y in zip(a, b):
         assert x["read_id"] == y["read_id"] and np.array_equal(x["signal"], y["signal"])
         assert x["digitisation"] == 8192.0 and x["sampling_rate"] == 4000.0 and abs(x["range"] - 1443.030273) < 1e-6
+
+
+def _cli_child(args, timeout=1500):
+    """`python -m seq2squiggle_amd predict ...` as a child process -> (seconds, its peak RSS in MB)."""
+    import resource
+    import time
+    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict"] + [str(a) for a in args], cwd=ROOT,
+                       capture_output=True, text=True, timeout=timeout)
+    el = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    peak = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss          # KB; the largest child so far
+    return el, peak / 1024.0, peak > before
+
+
+def test_config5_quarter_of_one_gpu_share(tmp_path):
+    """BASELINE.json configs[4] ("synthetic 100 Mb reference -c 30 -r 10000, pod5 out, 8 GPUs") at ONE QUARTER of one GPU's share:
+    the 300,000 reads of the full job are 37,500 per GPU; here a 3.125 Mb reference of 5 unequal contigs (rng 1234) with
+    `-c 30 -r 10000` gives round(30 * 3,125,000 / 10,000) = 9,375 reads (reference utils.py:509) ~ 5.9 M chunks ~ 1.1 G
+    samples through the CLI, streamed into .pod5 (VBZ rows) by run_streaming.  Checked: the read count, every read tiled
+    exactly by its signal-table rows, per-read sample counts AND sums equal to the same command written as .blow5, and the
+    host's peak RSS bounded well below the data volume (the reference keeps every read in RAM until one final save(),
+    inference.py:72-79 -- at this size 2.3 GB of int16 plus the fp32 tensors it was made from)."""
+    fasta = tmp_path / "ref.fasta"
+    lens = (1_000_000, 750_000, 625_000, 500_000, 250_000)
+    total = write_synthetic_reference(fasta, lens)
+    assert total == 3_125_000
+    c, r = 30, 10000
+    n_expected = round(c * total / r)
+    assert n_expected == 9375
+    ckpt = os.path.join(GOLDEN, "synthetic_k9.ckpt")
+    common = [fasta, "-c", c, "-r", r, "-m", ckpt, "--seed", 42, "-v", "warning"]
+    # RSS baseline: the same program on a job 1/100 the size (interpreter, torch, HIP runtime, pinned staging, the reference)
+    _, rss_small, _ = _cli_child([fasta, "-n", 94, "-r", r, "-m", ckpt, "--seed", 42, "-v", "warning", "-o", tmp_path / "small.pod5"])
+    t_pod5, rss_pod5, fresh = _cli_child(common + ["-o", tmp_path / "a.pod5"])
+    t_blow5, _, _ = _cli_child(common + ["-o", tmp_path / "b.blow5"])
+    size_pod5, size_blow5 = os.path.getsize(tmp_path / "a.pod5"), os.path.getsize(tmp_path / "b.blow5")
+    n = samples = rows = 0
+    blow = signal_io.iter_blow5(str(tmp_path / "b.blow5"))
+    next(blow)                                                              # header text
+    longest = 0
+    for (row, raw), b in zip(pod5_io.iter_pod5(str(tmp_path / "a.pod5")), blow):
+        assert row["read_number"] == n == b["read_number"] and str(row["read_id"]) == b["read_id"]
+        # the rows of a read tile it exactly: full rows of SIGNAL_CHUNK samples, then the remainder
+        assert len(raw) == row["num_samples"] == b["len_raw_signal"] > 0
+        assert len(row["signal"]) == -(-len(raw) // pod5_io.SIGNAL_CHUNK)
+        assert list(row["signal"]) == list(range(rows, rows + len(row["signal"])))
+        assert int(raw.astype(np.int64).sum()) == int(b["signal"].astype(np.int64).sum())
+        if n % 97 == 0:
+            assert np.array_equal(raw, b["signal"])
+        rows += len(row["signal"])
+        samples += len(raw)
+        longest = max(longest, len(raw))
+        n += 1
+    assert n == n_expected and next(blow, None) is None
+    chunks_lo = n * 450
+    assert samples > 150 * chunks_lo and longest > 3 * pod5_io.SIGNAL_CHUNK   # ~10 kb reads: several rows each, the longest many
+    raw_bytes = 2 * samples
+    assert size_pod5 < 0.75 * raw_bytes and size_blow5 < 0.85 * raw_bytes      # VBZ ~ 1.25 B/sample, zlib records ~ 1.55
+    # bounded memory: the big job may cost at most 1.2 GB more than the tiny one (its output alone is ~1.4 GB, the int16 samples
+    # 2.3 GB) -- reads are sampled lazily, super-batches are recycled, the POD5 writer keeps ~100 B per read until close()
+    print(f"config5/4: {n} reads, {samples} samples, pod5 {size_pod5 / 1e9:.2f} GB in {t_pod5:.1f} s, blow5 {size_blow5 / 1e9:.2f} GB in "
+          f"{t_blow5:.1f} s, peak RSS {rss_pod5:.0f} MB (small job {rss_small:.0f} MB)")
+    if fresh:
+        assert rss_pod5 < rss_small + 1200, (rss_pod5, rss_small)
+    assert rss_pod5 < 0.5 * raw_bytes / 2 ** 20 + rss_small
+
+
+def test_config1_exact_command(tmp_path):
+    """BASELINE.json configs[1], the configuration the headline metric is quoted on, as the command itself:
+    `seq2squiggle predict example/lamda_genome.fasta -n 1000 -r 5000` (default samplers, seed 42).  1000 reads and 286,622
+    chunks (the figure SURVEY 8d-M3 measured by importing the reference's sampler), every read present, and two runs write the
+    same samples and the same record draws."""
+    lam = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+    outs = []
+    for i in range(2):
+        chunks = _run(tmp_path / f"c1_{i}.blow5", lam, "dna-r10-prom", "synthetic_k9.ckpt", n=1000, r=5000, seed=42)
+        assert chunks == 286_622
+        outs.append(signal_io.read_blow5(str(tmp_path / f"c1_{i}.blow5"))[1])
+    a, b = outs
+    assert len(a) == len(b) == 1000 and [x["read_number"] for x in a] == list(range(1000))
+    assert len({x["read_id"] for x in a}) == 1000
+    for x, y in zip(a, b):
+        assert np.array_equal(x["signal"], y["signal"]) and x["offset"] == y["offset"] and x["median_before"] == y["median_before"]
+    n_samples = sum(len(x["signal"]) for x in a)
+    assert 150 * 286_622 < n_samples < 250 * 286_622

@@ -272,3 +272,32 @@ def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
         assert a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
         assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
     assert len({r["read_id"] for r in parts}) == 30
+
+
+def test_rank_shards_in_read_mode_skip_dropped_reads(tmp_path):
+    """--read-input with reads too short for one chunk scattered through the file (they produce no record,
+    reference dataloader.py:393-398): the shard writers must count RECORDS, not reads, so that ids, read numbers and
+    the per-record np.random draws of the 2-rank run still equal the single-process run's."""
+    rng = np.random.default_rng(17)
+    lines = []
+    for i in range(24):
+        n = 5 if i in (0, 3, 4, 11, 12, 20) else int(rng.integers(200, 1500))        # 5 < k = 9: dropped
+        lines.append(f">read{i}\n" + "".join(rng.choice(list("ACGT"), n)) + "\n")
+    fa = tmp_path / "reads.fasta"
+    fa.write_text("".join(lines))
+    base = [sys.executable, "-m", "seq2squiggle_amd", "predict", str(fa), "--read-input", "-m",
+            os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--seed", "5"]
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(base + ["-o", str(tmp_path / "one.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env0)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, one = signal_io.read_blow5(str(tmp_path / "one.blow5"))
+    parts = []
+    for rank in range(2):
+        env = dict(env0, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+        r = subprocess.run(base + ["-o", str(tmp_path / "out.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        parts += signal_io.read_blow5(str(tmp_path / f"out.rank{rank}.blow5"))[1]
+    assert len(parts) == len(one) == 18
+    for a, b in zip(parts, one):
+        assert np.array_equal(a["signal"], b["signal"]) and a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
+        assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]

@@ -125,3 +125,44 @@ def test_sharded_sampling_equals_slices_of_the_full_read_set(world):
         assert box["first"] == sum(-(-(max(L - 8, 0)) // 16) for L in ls[: len(got)])
         got += [s for s, _ in reads]
     assert got == full and any("N" in s for s in seqs)
+
+
+@pytest.mark.parametrize("profile,r,n_frac,min_len", [("dna-r10-prom", 3000, 0.04, 30), ("rna-004-prom", 2500, 0.02, 30),
+                                                      ("dna-r9-min", 300000, 0.0, 30), ("dna-r10-min", 400, 0.12, 300)])
+def test_native_replay_equals_the_interpreter_draw_for_draw(profile, r, n_frac, min_len):
+    """s2s_sampler_replay (the rank skip-ahead of sharded runs) against sampling_iter: same accepted-read lengths, same
+    index of the next read, and the SAME `random` generator state afterwards -- with N runs (extra draws), end-of-contig
+    rejections, N-rich rejections (> 10 % N), reads whose 20 retries all fail (-r 300000 on 7-30 kb contigs) and an RNA
+    profile (no strand draw, short reads allowed); also stopped part-way (stop_after) and resumed."""
+    rng = np.random.default_rng(11)
+    contigs = []
+    for L in (30000, 20000, 7000):
+        s = rng.choice(list("ACGT"), L)
+        if n_frac:
+            for lo in rng.integers(0, L - 400, 12):
+                s[lo: lo + int(rng.integers(1, 400))] = "N"
+            s[rng.random(L) < n_frac / 4] = "N"
+        contigs.append("".join(s))
+    seqs, lens = zip(*[U.process_genome(s) for s in contigs])
+    seqs, lens = list(seqs), list(lens)
+    total, seed, n = sum(lens), 77, 400
+    random.seed(seed)
+    want = U.sampling(n, seqs, lens, r, seed, total, "expon", profile, min_len, materialise=(0, 0))
+    end_state = random.getstate()
+    random.seed(seed)
+    got = U.replay_sampler(n, seqs, lens, r, seed, total, "expon", profile, min_len)
+    assert got is not None, "native replay unavailable"
+    assert got[0].tolist() == want and got[1] == n and random.getstate() == end_state
+    assert 0 < len(want) <= n and (r < 300000 or len(want) < n)                     # the 300 kb case loses reads to 20 failed retries
+    # stop part-way, then let the interpreter continue from there: the tail must be the same reads
+    k = len(want) // 3
+    random.seed(seed)
+    full = U.sampling(n, seqs, lens, r, seed, total, "expon", profile, min_len)
+    random.seed(seed)
+    part = U.replay_sampler(n, seqs, lens, r, seed, total, "expon", profile, min_len, stop_after=k)
+    assert part[0].tolist() == want[:k]
+    rest = list(U.sampling_iter(n, seqs, lens, r, seed, total, "expon", profile, min_len, first_read_i=part[1], n_accepted=k))
+    assert rest == full[k:] and random.getstate() == end_state
+    # cases the native path must decline (-> None): another length law, a seed beyond the scipy fast range
+    assert U.replay_sampler(n, seqs, lens, r, seed, total, "gamma", profile, min_len) is None
+    assert U.replay_sampler(n, seqs, lens, r, 2 ** 32 - 100, total, "expon", profile, min_len) is None
