@@ -71,36 +71,55 @@ def pmc_counters(mode, chunks_per_launch):
     return {"traffic": None, "mfma_busy": None, "valu_issue": None, "source": None}
 
 
-def end_to_end(mode):
-    """FASTA -> BLOW5 wall time through inference_run (engine creation, read sampling, chunking, the fused kernel, GPU
-    zero-strip + DAC, D2H, record compression, file write) for BASELINE.json configs[1] (lambda genome -n 1000 -r 5000,
-    default samplers) and for one GPU's share of configs[2] (12,500 of the 100,000 reads).  Reported beside the
-    resident-input kernel throughput, never as `value`.  Output goes to /dev/shm when it exists (the box's /tmp is an
-    overlay file system; the product writes wherever -o points)."""
+def _e2e_dirs():
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+
+
+def _e2e_run(mode, n_reads, ext="blow5", where="default", fasta=None, r=5000, c=-1):
+    """One inference_run (FASTA -> container file in a fresh temporary directory) -> (seconds, chunks, output bytes)."""
     import tempfile
     from seq2squiggle_amd.cli import set_config
     from seq2squiggle_amd.inference import inference_run
     from seq2squiggle_amd.utils import set_seeds
-    fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
-    out_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    fasta = fasta or os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
+    with tempfile.TemporaryDirectory(dir=_e2e_dirs() if where == "default" else where) as td:
+        out = os.path.join(td, "o." + ext)
+        set_seeds(42)
+        t0 = time.perf_counter()
+        m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
+                          fasta=fasta, read_input=False, n=n_reads, r=r, c=c, out=out, profile="dna-r10-prom",
+                          dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
+                          distr="expon", predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None,
+                          bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
+                          median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
+                          preserve_read_ids=False, seed=42, mode=mode)
+        el = time.perf_counter() - t0
+        size = os.path.getsize(out)
+        chunks = m.chunks_done
+        m.engine.close()
+    return el, chunks, size
 
-    def run(n_reads, ext="blow5", where=out_dir, fasta=fasta, r=5000, c=-1):
-        with tempfile.TemporaryDirectory(dir=where) as td:
-            out = os.path.join(td, "o." + ext)
-            set_seeds(42)
-            t0 = time.perf_counter()
-            m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
-                              fasta=fasta, read_input=False, n=n_reads, r=r, c=c, out=out, profile="dna-r10-prom",
-                              dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
-                              distr="expon", predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None,
-                              bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
-                              median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
-                              preserve_read_ids=False, seed=42, mode=mode)
-            el = time.perf_counter() - t0
-            size = os.path.getsize(out)
-            chunks = m.chunks_done
-            m.engine.close()
-        return el, chunks, size
+
+def end_to_end_one(n_reads, mode="f16x3"):
+    """A single rank's FASTA -> BLOW5 run of `n_reads` lambda reads (second, warm call timed): the yardstick the sharded legs and
+    tests/test_gpu_end_to_end.py compare with."""
+    _e2e_run(mode, min(n_reads, 1000))
+    el, chunks, size = _e2e_run(mode, n_reads)
+    return {"reads": n_reads, "seconds": el, "chunks": chunks, "chunks_per_sec": chunks / el, "output_bytes": size}
+
+
+def end_to_end(mode):
+    """FASTA -> BLOW5 wall time through inference_run (engine creation, read sampling, chunking, the fused kernel, GPU
+    zero-strip + DAC, D2H, record compression, file write) for BASELINE.json configs[1] (lambda genome -n 1000 -r 5000,
+    default samplers), for one GPU's share of configs[2] (12,500 of the 100,000 reads) and of configs[4] (37,500 10-kb reads
+    from a synthetic 12.5 Mb reference -> .pod5).  Reported beside the resident-input kernel throughput, never as `value`.
+    Output goes to /dev/shm when it exists, except where stated (`real_file_system`, `config5_share`: the default temp
+    directory, an overlay file system on the GPU boxes)."""
+    import tempfile
+    out_dir = _e2e_dirs()
+
+    def run(n_reads, ext="blow5", where=out_dir, fasta=None, r=5000, c=-1):
+        return _e2e_run(mode, n_reads, ext, where, fasta, r, c)
     first, _, _ = run(1000)            # the first call also pays the process's one-time costs (pinned buffers, thread pools)
     warm = [run(1000) for _ in range(3)]                # host-side timing moves by several ms from call to call: median of three
     el, chunks, size = sorted(warm)[1]
@@ -238,6 +257,62 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
             "sample": f"{done} chunks (batches of 1024, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
 
 
+def end_to_end_sharded(mode, dist, rank, world, dev):
+    """N > 1: what the resident-input `value` cannot show.  Every rank runs the real product path on ITS shard of BASELINE
+    configs[2] scaled to the rank count (lambda genome -n 12500 x world -r 5000: inference_run shards the read set by RANK /
+    WORLD_SIZE exactly as `torchrun ... seq2squiggle_amd predict` does -- shared seed, native sampler skip-ahead, per-rank
+    out.rankN.blow5 on /dev/shm), all ranks at once: host threads are cpu_share() = quota / LOCAL_WORLD_SIZE per rank, the
+    FASTA is parsed and the sampler replayed by every rank.  Wall = max over ranks between two barriers."""
+    import tempfile
+    from seq2squiggle_amd.cli import set_config
+    from seq2squiggle_amd.inference import inference_run
+    from seq2squiggle_amd.signal_io import cpu_share
+    from seq2squiggle_amd.utils import set_seeds
+    fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
+    out_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    n_total = 12500 * world
+
+    def run():
+        with tempfile.TemporaryDirectory(dir=out_dir) as td:
+            set_seeds(42)
+            dist.barrier()
+            t0 = time.perf_counter()
+            m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
+                              fasta=fasta, read_input=False, n=n_total, r=5000, c=-1, out=os.path.join(td, "o.blow5"),
+                              profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True,
+                              duration_sampling=True, distr="expon", predict_batch_size=1024, export_every_n_samples=1000000,
+                              sample_rate=None, bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
+                              median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
+                              preserve_read_ids=False, seed=42, mode=mode)
+            own = time.perf_counter() - t0
+            dist.barrier()
+            wall = time.perf_counter() - t0
+            first = m.first_global_chunk if hasattr(m, "first_global_chunk") else 0
+            chunks = m.chunks_done - first
+            size = sum(os.path.getsize(os.path.join(td, f)) for f in os.listdir(td))
+            m.engine.close()
+        return own, wall, chunks, size
+    run()                                  # the first call pays the process's one-time costs (pinned buffers, thread pools)
+    own, wall, chunks, size = run()
+    vals = torch.tensor([own, wall, float(chunks), float(size), float(cpu_share())], dtype=torch.float64,
+                        device=dev if dist.get_backend() == "nccl" else "cpu")
+    allv = [torch.zeros_like(vals) for _ in range(world)]
+    dist.all_gather(allv, vals)
+    if rank != 0:
+        return None
+    rows = [[float(x) for x in v.cpu()] for v in allv]
+    wall = max(r[1] for r in rows)
+    total = sum(r[2] for r in rows)
+    return {"workload": f"example lambda genome -n {n_total} -r 5000 -> out.rankN.blow5 on {out_dir or tempfile.gettempdir()}: "
+                        f"BASELINE configs[2]'s per-GPU share on each of {world} ranks, sharded by inference_run",
+            "seconds": wall, "chunks": total, "chunks_per_sec": total / wall, "reads_per_sec": n_total / wall,
+            "per_rank_seconds": [r[0] for r in rows], "per_rank_chunks": [r[2] for r in rows],
+            "per_rank_cpu_share_threads": [int(r[4]) for r in rows], "output_bytes": sum(r[3] for r in rows),
+            "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
+            "includes": "per rank: FASTA parse, sampler skip-ahead to its shard, engine creation, chunking, kernels, export, D2H, "
+                        "compression on cpu_share threads, file write"}
+
+
 WORKLOADS = {"config2": 1000, "config3": 12500}     # reads per GPU: BASELINE.json configs[1] / configs[2] (100,000 reads over 8 GPUs)
 
 
@@ -297,11 +372,19 @@ def main():
                               "sum_of_ones": int(t.item())}))
         dist.destroy_process_group()
         return
+    one_gpu = bool(os.environ.get("S2S_BENCH_ONE_GPU"))          # rehearsal on a 1-GPU box: every rank on cuda:0, barrier over gloo
+    if one_gpu:
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"                          # (inference_run picks its device from it)
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST"):      # (the env var exercises the RCCL calls on one GPU)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")                      # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    red_dev = "cpu" if one_gpu else None
 
     sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
     eng = S.Engine(sd, cfg, device=local, mode=a.mode)
@@ -337,11 +420,11 @@ def main():
     dec_ms, dec_launches, dec_chunks = eng.kernel_ms()
     ranks_seen, per_rank = 1, [B * a.steps / own]
     if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         ranks_seen = dist.get_world_size()
-        mine = torch.tensor([B * a.steps / own], dtype=torch.float64, device=dev)
+        mine = torch.tensor([B * a.steps / own], dtype=torch.float64, device=red_dev or dev)
         allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
         dist.all_gather(allr, mine)
         per_rank = [float(x.item()) for x in allr]
@@ -360,6 +443,9 @@ def main():
         torch.cuda.synchronize()
         small_rate = reps * small / (time.perf_counter() - t1)
 
+    sharded = None
+    if dist and world > 1 and not a.no_cpu_baseline:
+        sharded = end_to_end_sharded(a.mode, dist, rank, world, dev)
     if rank == 0:
         chunks_total = B * a.steps * world
         chunks_s = chunks_total / el
@@ -402,6 +488,11 @@ def main():
             "chunks_per_sec_at_reference_batch_1024": small_rate,
             "roofline": roof,
         }
+        if sharded:
+            out["end_to_end_sharded"] = sharded
+            out["end_to_end_sharded"]["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
+        if one_gpu:
+            out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 (gloo barrier) -- NOT a scaling measurement"
         if world == 1 and not a.no_cpu_baseline:
             out["end_to_end"] = end_to_end(a.mode)
             out["cpu_baseline"] = cpu_baseline(sd, cfg, eng)

@@ -241,10 +241,10 @@ int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32
                            uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
                            int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i);
 
-/* Diagnostic builds (-DS2S_DIAG, never the shipped library): 48 per-phase wave-cycle sums since the
- * last call (0-15 decoder, 16-31 unused, 32-47 the frontend's own
- * phases; tools/diag_phases.py names them); S2S_ERR_ARG in a normal build. */
-int s2s_diag_read(s2s_handle* h, uint64_t* out48);
+/* Diagnostic builds (-DS2S_DIAG, never the shipped library): per wave of a workgroup (8 rows) 48 per-phase shader-cycle sums
+ * since the last call, summed over the workgroups (slots 0-15 decoder phases, 16-18 whole-kernel s_memtime / s_memrealtime /
+ * wave count, 32-47 the frontend's own phases; tools/diag_phases.py names them); out384 = [8][48].  S2S_ERR_ARG in a normal build. */
+int s2s_diag_read(s2s_handle* h, uint64_t* out384);
 
 #ifdef __cplusplus
 }

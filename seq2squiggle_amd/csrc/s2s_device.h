@@ -45,23 +45,44 @@ struct DebugDev {
     unsigned long long* diag;       // S2S_DIAG builds only
 };
 
+// ReLU as an integer max on the bit pattern (v_max_i32: negative floats have the sign bit set, i.e. are negative integers):
+// one VOP2 instruction.  fmaxf(x, 0.0f) compiles to TWO -- the IEEE maxNum semantics make the compiler quiet a possible
+// signalling NaN first (v_max_f32 x, x, x), which it cannot rule out for a value that comes out of an MFMA: 590 such
+// instructions in the f16x3 kernel, 256 of them per wave and chunk in the FFN loops.  Same bits for every non-NaN input.
+__device__ __forceinline__ float relu1(const float x) {
+#ifdef S2S_RELU_FMAX
+    return fmaxf(x, 0.0f);
+#else
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+#endif
+}
+
 #ifdef S2S_DIAG
-// diagnostic build only: per-phase wave-cycle sums (s_memtime) into a side buffer no other code reads
-#define DIAG_DECL unsigned long long diag_t_ = clock64()
+// diagnostic build only: per-phase wave-cycle sums (s_memtime = shader-clock cycles).  Every wave adds into ITS OWN row of a small
+// LDS table (one lane, plain read-modify-write: no contention, no global traffic in the hot loop -- round 2's version sent a
+// global atomicAdd per stamp from 2,048 waves to 16 hot addresses, which slowed the diagnostic build 5x and inflated the phases
+// that stamp most often); the kernel folds the table into the global side buffer once, when it ends.
+#define S2S_DIAG_SLOTS 48
+__shared__ unsigned long long s2s_diag_lds[8 * S2S_DIAG_SLOTS];
+#define DIAG_DECL unsigned long long diag_t_ = __builtin_readcyclecounter()
 #define DIAG_STAMP(slot)                                                            \
     do {                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                          \
-        const unsigned long long n_ = clock64();                                    \
-        if (diag_buf && (threadIdx.x & 63) == 0) atomicAdd(diag_buf + (slot), n_ - diag_t_); \
+        const unsigned long long n_ = __builtin_readcyclecounter();                 \
+        if ((threadIdx.x & 63) == 0) s2s_diag_lds[(threadIdx.x >> 6) * S2S_DIAG_SLOTS + (slot)] += n_ - diag_t_; \
         diag_t_ = n_;                                                               \
         __builtin_amdgcn_sched_barrier(0);                                          \
     } while (0)
+#define DIAG_COUNT(slot, n) do { if ((threadIdx.x & 63) == 0) s2s_diag_lds[(threadIdx.x >> 6) * S2S_DIAG_SLOTS + (slot)] += (n); } while (0)
 #elif defined(S2S_STAMP_SB)
 #define DIAG_DECL
 #define DIAG_STAMP(slot) __builtin_amdgcn_sched_barrier(0)
+#define DIAG_COUNT(slot, n)
 #else
 #define DIAG_DECL
 #define DIAG_STAMP(slot)
+#define DIAG_COUNT(slot, n)
 #endif
 
 #ifndef S2S_ABL
@@ -466,7 +487,7 @@ __device__ __forceinline__ void fft_block(const float* __restrict__ W, const Lay
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = relu1(t[q][r]);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..

@@ -33,6 +33,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define S2S_FFN_LDS 1           // decoder FFN weights staged once per workgroup in the dead K/V region (0: every wave streams them from L2)
 #endif
 #define S2S_PF_FLOATS (1024 + 16 + 16)   // one frontend -> decoder hand-off slot (s2s_hip.hip: S2S_SLOT_FLOATS)
+#define S2S_PROG_INTS 16                 // per-wave progress counters of the attention loop (S2S_PRIO_MODE 4 / 5), behind the small vectors
 #define S2S_SV_FLOATS 960                // bq_nat, bk_nat, bq, bk, bv, bfc (64 each), b1 (256), b2, ln1g, ln1b, ln2g, ln2b (64 each)
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
 // Scheduling barriers pin the weight-unit / K,V-fragment loads in front of the MFMAs they are prefetched behind; the
@@ -53,6 +54,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef S2S_ATT32_MSLOT
 #define S2S_ATT32_MSLOT 1
+#endif
+#ifndef S2S_ATT_PIPE
+#define S2S_ATT_PIPE 0          // > 0: the tile-pipelined fast softmax path (softmax_pv32), value = vector instructions per MFMA in its pattern
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMAW(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -333,6 +337,8 @@ __device__ __forceinline__ float sum_h(float v) {
     auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
+__device__ __forceinline__ h8 opaque8(h8 x) { asm volatile("" : "+v"(x)); return x; }   // (timing ablations: a value the optimiser cannot see through)
+__device__ __forceinline__ h8 P_last(const unsigned (&x)[4]) { return __builtin_bit_cast(h8, (uv4{x[0], x[1], x[2], x[3]})); }
 template <int TV, bool SAFE, bool LO>
 __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
                                              const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
@@ -361,6 +367,118 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     };
     f32x16 negm = zero16;
     h8 qb2m = qb2;
+#if S2S_ATT_PIPE
+    if constexpr (!SAFE && LO) {
+        // Software-pipelined fast path, one 32-key tile per stage, IN THE ORDER WRITTEN: every group of statements below is fenced by
+        // a scheduling barrier, so hipcc only allocates registers and inserts the hazard wait states.  While tile t's 16 scores per
+        // lane go through v_exp / v_cvt_pk / v_fma_mix and its four P.V MFMAs, the two score MFMAs of tile t+1 are in flight and
+        // the LDS reads of tile t+2's K rows and tile t+1's V rows have been issued.  The six MFMAs of a stage sit 6-9 vector
+        // instructions apart: never two back to back (a wave that waits for the matrix pipe at the issue port also stops the other
+        // wave of its SIMD), and a lone wave never waits for an LDS round trip or a score chain in front of its exponentials.
+        // tools/probes/pass_probe.hip measured this order against the one hipcc picks for the two-tile pass below: 1470 against
+        // 1774 cycles per 64 keys with two waves per SIMD, 816 against 1116 for a lone wave.  Same operations in the same order
+        // per accumulator as the pass below, hence the same bits.
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+        auto kb_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp2 + t * (h ? 0 : 32 * 8)); };
+        h8 ka[NT], kb[NT], va[NT][2];
+        f32x16 sc[NT];
+        ka[0] = k_of(0); kb[0] = kb_of(0); ka[1] = k_of(1); kb[1] = kb_of(1);
+        va[0][0] = v_of(0, 0); va[0][1] = v_of(0, 1);
+        SBAR();
+        {   // raw scores of the first 64 keys -> the shift (column max + head-room), riding in the second score MFMA from here on
+            f32x16 r0 = MFMAW(ka[0], qb1, zero16);
+            f32x16 r1 = MFMAW(ka[1], qb1, zero16);
+            r0 = MFMAW(kb[0], qb2, r0);
+            r1 = MFMAW(kb[1], qb2, r1);
+            SBAR();
+            float mh = r0[0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mh = fmaxf(mh, fmaxf(r0[r], r1[r]));
+            const float nm = -(max_h(mh) + S2S_SHIFT_BIAS);
+            const _Float16 nh = (_Float16)nm;
+            const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, (_Float16)(nm - (float)nh)}));
+            uv4 q2 = __builtin_bit_cast(uv4, qb2);
+            q2[0] = h ? pk : q2[0];
+            qb2m = __builtin_bit_cast(h8, q2);
+        }
+        SBAR();
+        sc[0] = MFMAW(kb[0], qb2m, MFMAW(ka[0], qb1, zero16));
+        SBAR();
+        unsigned ph[2][4], pl[2][4];                 // the P operands of the current tile: [16-key step][4 packed pairs]
+        h8 va_prev1 = va[0][1];
+        unsigned pl_prev[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t == NT - 1) mask_last(sc[t]);
+            float e[16];
+            auto exps = [&](const int lo_, const int hi_) {
+#pragma unroll
+                for (int i = lo_; i < hi_; ++i) e[i] = __builtin_amdgcn_exp2f(sc[t][i]);
+            };
+            auto cvts = [&](const int st) {          // v_cvt_pk_f16_f32 x4: the hi halves of 8 probabilities
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned hb = __builtin_bit_cast(unsigned, (h2v{(_Float16)e[8 * st + 2 * j], (_Float16)e[8 * st + 2 * j + 1]}));
+                    asm("" : "+v"(hb));
+                    ph[st][j] = hb;
+                }
+            };
+            auto mixes = [&](const int st, const int j0, const int j1) {     // v_fma_mixlo / mixhi: the lo halves (see split2)
+#pragma unroll
+                for (int j = j0; j < j1; ++j) {
+                    const h2v hv = __builtin_bit_cast(h2v, ph[st][j]);
+                    const h2v l = {(_Float16)__builtin_fmaf(e[8 * st + 2 * j], one, -(float)hv[0]),
+                                   (_Float16)__builtin_fmaf(e[8 * st + 2 * j + 1], one, -(float)hv[1])};
+                    pl[st][j] = __builtin_bit_cast(unsigned, l);
+                }
+            };
+            auto P = [&](const unsigned (&x)[4]) { return __builtin_bit_cast(h8, (uv4{x[0], x[1], x[2], x[3]})); };
+            // ---- vector instructions 0-1, K(t+2) reads, then the previous tile's last P.V MFMA
+            if (t + 2 < NT) ka[t + 2] = (S2S_ABL & (1 << 17)) ? opaque8(qb1) : k_of(t + 2);
+            exps(0, 2);
+            SBAR();
+            if (t > 0) { O = MFMAW(va_prev1, P(pl_prev), O); }
+            SBAR();
+            exps(2, 8);
+            if (t + 2 < NT) kb[t + 2] = (S2S_ABL & (1 << 17)) ? opaque8(qb2) : kb_of(t + 2);
+            SBAR();
+            if (t + 1 < NT) {
+                if (S2S_ABL & (1 << 18)) { f32x16 tmp_ = sc[0]; asm volatile("" : "+v"(tmp_)); sc[t + 1] = tmp_; }   // (timing only: no score MFMAs)
+                else sc[t + 1] = MFMAW(ka[t + 1], qb1, zero16);                  // score MFMA 1 of the next tile
+            }
+            SBAR();
+            cvts(0);
+            mixes(0, 0, 1);
+            SBAR();
+            if (t + 1 < NT && !(S2S_ABL & (1 << 18))) sc[t + 1] = MFMAW(kb[t + 1], qb2m, sc[t + 1]);   // score MFMA 2
+            SBAR();
+            mixes(0, 1, 4);
+            exps(8, 9);
+            SBAR();
+            O = MFMAW(va[t][0], P(ph[0]), O);
+            SBAR();
+            exps(9, 16);
+            if (t + 1 < NT) va[t + 1][0] = (S2S_ABL & (1 << 19)) ? opaque8(qb1) : v_of(t + 1, 0);
+            cvts(1);
+            // (two of the four)
+            SBAR();
+            O = MFMAW(va[t][0], P(pl[0]), O);
+            SBAR();
+            mixes(1, 0, 2);
+            if (t + 1 < NT) va[t + 1][1] = (S2S_ABL & (1 << 19)) ? opaque8(qb2) : v_of(t + 1, 1);
+            SBAR();
+            O = MFMAW(va[t][1], P(ph[1]), O);
+            SBAR();
+            mixes(1, 2, 4);
+            SBAR();
+            va_prev1 = va[t][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pl_prev[j] = pl[1][j];
+        }
+        O = MFMAW(va_prev1, P_last(pl_prev), O);
+#undef SBAR
+    } else
+#endif
     if constexpr (!SAFE) {
         // fast path: the shift is pass 0's column max (+ head-room), later passes compute no max at all.  Two tiles (64 keys) per
         // pass, as straight-line code.  (Measured: issuing tile t+1's score MFMAs ahead of tile t's exponentials by hand -- no
@@ -465,6 +583,21 @@ template <class G> __device__ __forceinline__ void att32_consts(char* __restrict
         for (int i = tid; i < 3 * G::VS; i += nthreads)
             cr[i] = (i < G::VS || (i >= 2 * G::VS && ((i - 2 * G::VS) & 7) < 2)) ? (_Float16)1.0f : (_Float16)0.0f;
     }
+}
+
+// ---- wave balancing inside a SIMD (S2S_PRIO_MODE >= 4).  The two waves of a SIMD run the same attention loop, and the SIMD's
+// arbiter always prefers the OLDER wave (waves 0-3 of the workgroup): it runs at the speed of a lone wave, the younger one only
+// fills its stalls, and once the older wave has reached the barrier behind the loop the younger one runs alone with all of its
+// own stalls exposed (measured with the per-wave phase stamps: 79 k against 126 k cycles per chunk in the loop, 48 k of barrier
+// wait for the older wave).  Here every wave counts the heads it has finished in an LDS word and raises its priority whenever
+// it is not ahead of its partner (wave ^ 4), so that the two alternate as the favoured wave and reach the barrier together.
+__device__ __forceinline__ void prio_balance(int* __restrict__ prog, const int wave) {
+    const int lane = threadIdx.x & 63;
+    int mine = prog[wave] + 1;
+    if (lane == 0) prog[wave] = mine;
+    const int theirs = __builtin_amdgcn_readfirstlane(prog[wave ^ 4]);
+    mine = __builtin_amdgcn_readfirstlane(mine);
+    if (mine <= theirs) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 }
 
 // A weight unit of the f16 streams: [kb0 hi][kb0 lo][kb1 hi][kb1 lo] (4 KiB), or, for the single-product mode, the hi-only
@@ -572,12 +705,18 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     h8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+#ifndef S2S_PRIO_MODE
+#define S2S_PRIO_MODE 0      // experiments on the SIMD's wave arbitration during the attention loop
+#endif
 #pragma unroll 1
     for (int u = 0; u < 2; ++u) {                     // two head pairs per iteration = one K = 32 block of fc
         f32x4 opair[2][NQ];
+        if (S2S_PRIO_MODE == 1 && WAVES == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); }
+        if (S2S_PRIO_MODE == 2 && WAVES == 8) { if ((wave >= 4) == (u == 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int p = 2 * u + pp;
+            if (S2S_PRIO_MODE == 3 && WAVES == 8) { if ((wave >= 4) == (pp == 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
             if (pp == 0) { load_unit_h<LO>(fb, ws); WS_ADVP(UF, 8192); } else { load_unit_h<LO>(fa, ws); WS_ADVP(UF, 8192); }
             const f32x4 bq = ldg4(svp(L.bq_nat) + 16 * p + 4 * g);   // (pack_layer: Wq and bq of the f16 streams carry the log2(e)/sqrt(d_k) factor)
@@ -604,6 +743,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int head = 2 * p + hh;
+                    if constexpr (S2S_PRIO_MODE >= 4 && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS), wave);
                     const _Float16* qrow = Ql + (((hh * NQ + (n >> 4)) * 2 + 0) * 16 + (n & 15)) * 8;      // [head of the pair][q][hi|lo][c][8 d]
                     const h8 qb1 = *reinterpret_cast<const h8*>(qrow);
                     const h8 qb2 = *reinterpret_cast<const h8*>(hl ? crow + G::VS : qrow + 16 * 8);
@@ -617,7 +757,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     {
                         const bool redo = __any(!(lsum <= 3.0e38f));       // inf or NaN row sum: some P_hi left the f16 range
 #ifdef S2S_DIAG
-                        if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
+                        DIAG_COUNT(11, 1ull); if (redo) DIAG_COUNT(10, 1ull);
 #endif
                         if (__builtin_expect(redo, 0)) {
                             softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
@@ -658,7 +798,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     for (int q = 0; q < NQ; ++q) bad = bad || !(lH[q][0] + (LO ? lL[q][0] : 0.0f) <= 3.0e38f);
                     const bool redo = __any(bad);
 #ifdef S2S_DIAG
-                    if (diag_buf && lane == 0) { atomicAdd(diag_buf + 11, 1ull); if (redo) atomicAdd(diag_buf + 10, 1ull); }
+                    DIAG_COUNT(11, 1ull); if (redo) DIAG_COUNT(10, 1ull);
 #endif
                     if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
                 }
@@ -715,6 +855,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             }
         }
     }
+    if (S2S_PRIO_MODE != 0 && WAVES == 8) __builtin_amdgcn_s_setprio(0);
     if constexpr (!(S2S_FFN_LDS && WAVES == 8 && LO)) DIAG_STAMP(3);
 
     // ---- FFN 64 -> 256 -> 64 in four 64-wide slices of the hidden layer (layers.py:108-113)
@@ -813,7 +954,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = relu1(t[q][r]);
         }
         HL hb[NQ][2];
 #pragma unroll
@@ -1005,7 +1146,7 @@ __device__ __forceinline__ void enc_ffn_half_h(const float* __restrict__ W, cons
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = fmaxf(t[q][r], 0.0f);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = relu1(t[q][r]);
         }
         HL hb[NQ][2];
 #pragma unroll

@@ -32,7 +32,7 @@ __device__ __forceinline__ void relu_tiles(f32x4 (&x)[NQ][4]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[q][mt][r] = fmaxf(x[q][mt][r], 0.0f);
+            for (int r = 0; r < 4; ++r) x[q][mt][r] = relu1(x[q][mt][r]);
 }
 
 __device__ __forceinline__ int base_code(unsigned char ch) {       // utils.py:74 letter_to_int
@@ -222,13 +222,11 @@ template <int NQ>
 __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __restrict__ W, const FrontChunk (&io)[NQ],
                                              const ParamsDev& P, const DebugDev& dbg, const int lane, const float one) {
     const int g = lane >> 4, c = lane & 15;
-#ifdef S2S_DIAG
-    unsigned long long* diag_buf = dbg.diag ? dbg.diag + 32 : nullptr;
-#endif
     DIAG_DECL;
+#define FDIAG(slot) DIAG_STAMP(32 + (slot))
     f32x4 X[NQ][4];
     front_embed<NQ>(M, W, io, lane, X);
-    DIAG_STAMP(0);
+    FDIAG(0);
 #pragma unroll 1
     for (int i = 0; i < M.pre_layers; ++i) {                         // modules.py:74-77
         HL xb[NQ][2];
@@ -243,7 +241,7 @@ __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __r
             for (int mt = 0; mt < 4; ++mt) X[q][mt] = Y[q][mt];
     }
     front_store<NQ>(io, dbg, X, lane, false);                        // emb_out (debug only)
-    DIAG_STAMP(1);
+    FDIAG(1);
     {   // the three heads read emb_out only (modules.py:275-278, 197-225), so they run BEFORE the encoder blocks: emb_out is dead
         // by then instead of being carried (and spilled) through them
         HL Sb[NQ][2];
@@ -259,7 +257,7 @@ __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __r
         };
         head(M.noise, sig);
         if (P.duration_sampling) { head(M.conc, cq); head(M.rate, rq); }
-        DIAG_STAMP(4);
+        FDIAG(4);
         front_dwell<NQ>(io, P, sig, cq, rq, dbg, lane);
     }
 #pragma unroll
@@ -268,7 +266,7 @@ __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __r
 #pragma unroll
         for (int q = 0; q < NQ; ++q) X[q][ft] += pe;                 // modules.py:80
     }
-    DIAG_STAMP(5);
+    FDIAG(5);
 #pragma unroll 1
     for (int l = 0; l < M.enc_layers; ++l) {
         const LayerOff L = M.enc[l];
@@ -276,12 +274,12 @@ __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __r
         f32x4 acc[NQ][4];
         HL x1b[NQ][2];
         enc_attention_h<NQ>(W, L, wl, X, acc, lane, one);
-        DIAG_STAMP(2);
+        FDIAG(2);
         enc_ffn_begin_h<NQ>(W, L, acc, X, x1b, lane, one);
         enc_ffn_half_h<NQ>(W, L, wl + 16 * 1024, 0, x1b, X, lane, one);
         enc_ffn_half_h<NQ>(W, L, wl + 32 * 1024, 2, x1b, X, lane, one);
         layer_norm64<NQ, true>(X, W + L.ln2g, W + L.ln2b, g);
-        DIAG_STAMP(3);
+        FDIAG(3);
     }
     front_store<NQ>(io, dbg, X, lane, true);
 }
@@ -390,7 +388,7 @@ __device__ __forceinline__ void dec_project(const ModelDev& M, const float* __re
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part += X[q][ft][r] * wo[ft][r];
-        const float v = fmaxf(sum_g(part) + bo, 0.0f);
+        const float v = relu1(sum_g(part) + bo);
         if (g == q) { ys = v; se = sig_ext[q]; }
     }
 }
@@ -436,7 +434,7 @@ template <int MODE> struct Fused {
     static constexpr int FNQ = (FMODE == 1) ? 2 : 1;              // chunks per frontend wave
     static constexpr int GROUP = DEC_WAVES * FNQ;
     static constexpr bool PF = (MODE == 1);                       // next chunk's slot prefetched into LDS (dec_blocks)
-    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS) * 4;   // + next slot, small vectors
+    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS + S2S_PROG_INTS) * 4;   // + next slot, small vectors, progress counters
     static_assert(LDS <= 160 * 1024, "LDS per workgroup");
     static_assert(FMODE == 1 || DEC_WAVES * FrontLdsF32::BYTES <= LDS, "the f32 frontend waves' K/V images share the decoder's LDS");
 };
@@ -461,6 +459,15 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
     const int lane = threadIdx.x & 63;
     const int nb = S2S_T_ENC + M.k - 1;
     if constexpr (MODE != 0) att32_consts<AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>>(lds_raw, threadIdx.x, DEC_WAVES * 64);   // (visible after the group loop's first barrier)
+    if constexpr (MODE != 0) {                                     // the attention loop's progress counters (prio_balance)
+        if (threadIdx.x < S2S_PROG_INTS)
+            reinterpret_cast<int*>(lds_raw + DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS) * 4)[threadIdx.x] = 0;
+    }
+#ifdef S2S_DIAG
+    for (int i = threadIdx.x; i < 8 * S2S_DIAG_SLOTS; i += DEC_WAVES * 64) s2s_diag_lds[i] = 0;
+    const unsigned long long diag_c0 = __builtin_readcyclecounter(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+#endif
     float* const slot0 = handoff + (size_t)blockIdx.x * S2S_MAX_GROUP * S2S_SLOT_FLOATS;
     const int lo = (int)((long long)blockIdx.x * n_chunks / gridDim.x), hi = (int)((long long)(blockIdx.x + 1) * n_chunks / gridDim.x);
 #pragma unroll 1
@@ -468,9 +475,6 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         const int n_here = hi - g0 < F::GROUP ? hi - g0 : F::GROUP;
         float one = 1.0f;                  // opaque to the optimiser: see split2 in s2s_device_h.h
         asm volatile("" : "+s"(one));
-#ifdef S2S_DIAG
-        unsigned long long* diag_buf = dbg.diag;
-#endif
         DIAG_DECL;
         __syncthreads();                   // the previous group's last block is done with the K/V region and with the slots
         {
@@ -535,6 +539,17 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
             DIAG_STAMP(9);
         }
     }
+#ifdef S2S_DIAG
+    // slots 16 / 17: this wave's whole-kernel time on the shader clock (s_memtime) and on the constant 100 MHz clock (s_memrealtime):
+    // their ratio is the clock the SIMDs actually ran at (MI355X_MICROARCH.md, DVFS)
+    DIAG_COUNT(16, __builtin_readcyclecounter() - diag_c0);
+    DIAG_COUNT(17, __builtin_amdgcn_s_memrealtime() - diag_r0);
+    DIAG_COUNT(18, 1ull);
+    __syncthreads();
+    if (dbg.diag)
+        for (int i = threadIdx.x; i < 8 * S2S_DIAG_SLOTS; i += DEC_WAVES * 64)
+            if (s2s_diag_lds[i]) atomicAdd(dbg.diag + i, s2s_diag_lds[i]);        // [wave][slot], summed over the workgroups
+#endif
 }
 
 // ================================================================================ export
@@ -738,7 +753,7 @@ struct s2s_handle {
     int* ws_svb = nullptr;            // s2s_svb_encode scratch: bytes per row
     int ws_svb_cap = 0;
     bool profiling = false;
-    unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: 16 per-phase wave-cycle sums
+    unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: [8 waves][48] per-phase wave-cycle sums
     std::vector<EventPair> events;
     std::string err;
 };
@@ -1118,8 +1133,8 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
         if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(dynamic LDS)");
 #ifdef S2S_DIAG
-    if ((e = hipMalloc(&h->d_diag, 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
-    if ((e = hipMemset(h->d_diag, 0, 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
+    if ((e = hipMalloc(&h->d_diag, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
+    if ((e = hipMemset(h->d_diag, 0, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
 #endif
     *out = h;
     return S2S_OK;
@@ -1323,8 +1338,8 @@ int s2s_diag_read(s2s_handle* h, uint64_t* out48) {
     if (!h || !out48) return S2S_ERR_ARG;
     if (!h->d_diag) return fail(h, S2S_ERR_ARG, "not a diagnostic (-DS2S_DIAG) build");
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out48, h->d_diag, 48 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemset(h->d_diag, 0, 48 * sizeof(uint64_t)));
+    HIP_TRY(h, hipMemcpy(out48, h->d_diag, 8 * 48 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemset(h->d_diag, 0, 8 * 48 * sizeof(uint64_t)));
     return S2S_OK;
 }
 

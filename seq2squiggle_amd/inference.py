@@ -397,6 +397,7 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
         writer.start_at(first_read)            # read ids / read_number / record draws continue the single-process run
     load_model = loading.result()
     load_model.chunks_done = int(first_chunk)  # global chunk index of this rank's first chunk: keys the device RNG counters
+    load_model.first_global_chunk = int(first_chunk)
     check_model(load_model, config)
 
     n_chunks = 0

@@ -85,6 +85,8 @@ def cpu_share() -> int:
     """Worker threads this process may keep busy: the cores it is allowed on, capped by the container's CPU quota (cgroup
     cpu.max -- more runnable threads than the quota buys get the whole group throttled for the rest of the scheduler period,
     a stall of tens of milliseconds), divided between the ranks of a multi-process run on this node."""
+    if os.environ.get("S2S_CPU_SHARE"):                # explicit override (tools/host_scaling.py: what if a rank only gets n threads?)
+        return max(1, int(os.environ["S2S_CPU_SHARE"]))
     cores = len(os.sched_getaffinity(0))
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:                          # cgroup v2: "<quota> <period>" | "max <period>"

@@ -3,6 +3,7 @@
 Deterministic configuration (BASELINE.json configs[0]: example/test.fasta --read-input, samplers off, ideal
 dwell): the reference's own predict_step output for these chunks is the golden `y_ideal`; per read the expected
 file content is zero-strip + DAC of those rows (both pinned separately against the reference)."""
+import json
 import os
 import subprocess
 import sys
@@ -301,3 +302,37 @@ def test_rank_shards_in_read_mode_skip_dropped_reads(tmp_path):
     for a, b in zip(parts, one):
         assert np.array_equal(a["signal"], b["signal"]) and a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
         assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
+
+
+def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver starts it (children of an untouched parent, torchrun rendezvous on
+    127.0.0.1), rehearsed on this box's ONE GPU (S2S_BENCH_ONE_GPU: both ranks on cuda:0, gloo barrier -- RCCL refuses two
+    ranks per device).  It cannot measure scaling (the ranks share the GPU) but it runs everything the 8-GPU line will run:
+    the N > 1 code path of the timed loop, the sharded end-to-end leg (each rank: FASTA parse, native sampler skip-ahead,
+    its read shard, cpu_share() = quota / LOCAL_WORLD_SIZE threads, its own shard file) and the max-over-ranks timing.
+    Checked: one JSON line, both ranks seen, the shards add up to the whole job, and two ranks sharing one GPU move at
+    least 80 % of what one rank moves end to end (a host-side collapse under halved thread counts would show here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["S2S_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "500"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and len(d["per_rank_chunks_per_sec"]) == 2
+    assert "end_to_end" not in d and "cpu_baseline" not in d
+    e = d["end_to_end_sharded"]
+    # lambda genome -n 25000 -r 5000, seed 42: the read set of the single-process run, split in two contiguous shards
+    assert len(e["per_rank_chunks"]) == 2 and abs(e["per_rank_chunks"][0] - e["per_rank_chunks"][1]) < 0.02 * e["chunks"]
+    assert 6_900_000 < e["chunks"] < 7_300_000 and e["output_bytes"] > 2.5e9
+    assert e["per_rank_cpu_share_threads"][0] == e["per_rank_cpu_share_threads"][1] >= 1 and e["local_world_size"] == 2
+    one = subprocess.run([sys.executable, "-c", (
+        "import json,sys,os;sys.path.insert(0,%r);import bench;e=bench.end_to_end_one(12500);print(json.dumps(e))" % ROOT)],
+        cwd=ROOT, capture_output=True, text=True, timeout=900, env={k: v for k, v in env.items() if k != "S2S_BENCH_ONE_GPU"})
+    assert one.returncode == 0, one.stderr[-3000:]
+    single = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    ratio = e["chunks_per_sec"] / single["chunks_per_sec"]
+    print(f"two ranks on one GPU: {e['chunks_per_sec']:.3e} chunks/s end to end ({e['per_rank_cpu_share_threads'][0]} host threads per rank) "
+          f"vs one rank {single['chunks_per_sec']:.3e}: x{ratio:.2f}")
+    assert ratio > 0.8, (e, single)
