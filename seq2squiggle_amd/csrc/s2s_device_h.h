@@ -33,6 +33,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define S2S_FFN_LDS 1           // decoder FFN weights staged once per workgroup in the dead K/V region (0: every wave streams them from L2)
 #endif
 #define S2S_PF_FLOATS (1024 + 16 + 16)   // one frontend -> decoder hand-off slot (s2s_hip.hip: S2S_SLOT_FLOATS)
+#define S2S_Z2_FLOATS (256 + 64)         // a second all-zeros V^T row (264 halves) + room to start it on 16-byte bank slot 4: see vp in fft_block_h
 #define S2S_PROG_INTS 16                 // per-wave progress counters of the attention loop (S2S_PRIO_MODE 4 / 5), behind the small vectors
 #define S2S_SV_FLOATS 960                // bq_nat, bk_nat, bq, bk, bv, bfc (64 each), b1 (256), b2, ln1g, ln1b, ln2g, ln2b (64 each)
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
@@ -54,6 +55,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef S2S_ATT32_MSLOT
 #define S2S_ATT32_MSLOT 1
+#endif
+#ifndef S2S_ONE_ZEROS_ROW
+#define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
+#endif
+#ifndef S2S_KB_SELECT
+#define S2S_KB_SELECT 0
 #endif
 #ifndef S2S_ATT_PIPE
 #define S2S_ATT_PIPE 0          // > 0: the tile-pipelined fast softmax path (softmax_pv32), value = vector instructions per MFMA in its pattern
@@ -136,14 +143,15 @@ template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
     static constexpr bool V128 = (NKT % 2) == 0;
     // ATT32 (the decoder with S2S_ATT32): the attention core runs on v_mfma_f32_32x32x16_f16 (softmax_pv32).  A V^T row is then
     // stored as [16-key step][lane half h][8 halves] -- keys 4h..4h+3 and 8+4h..8+4h+3 of the step: the 8 k-slots a lane half feeds
-    // -- 264 halves = 132 dwords == 4 (mod 64): the 16 rows of a ds_read_b128 land in 16 distinct 4-dword bank slots.  Three
-    // constant rows follow the V region (all ones: the A-operand row that makes the MFMA add up P; all zeros: rows 17-31 of that
+    // -- 264 halves = 132 dwords == 4 (mod 64): V^T row r lands in 16-byte bank slot r mod 16, so the 16 data rows of a head never collide
+    // (the constant rows the other lanes read are placed per lane group: see vp in fft_block_h).  Constant rows follow the V region (all ones: the A-operand row that makes the MFMA add up P; all zeros: rows 17-31 of that
     // operand and the unused k-slots of the second Q operand; {1, 1, 0, 0, 0, 0, 0, 0} repeated: the k-slots of the second score
     // MFMA's A operand that take the softmax shift), written once per kernel (att32_consts).
     static constexpr bool ATT32 = S2S_ATT32 && NQ == 2 && NKT == 16;
     static constexpr int VS = ATT32 ? KEYS + 8 : V128 ? KEYS + 16 : KEYS + 8;
     static constexpr int V_BYTES = 8 * 16 * VS * 2;
-    static constexpr int C_BYTES = ATT32 ? 3 * VS * 2 : 0;         // rows: ones | zeros | {1, 1, 0, 0, 0, 0, 0, 0} repeated
+    static constexpr int C_ROWS = 3;                               // rows: ones | zeros | {1, 1, 0, 0, 0, 0, 0, 0} repeated (a second zeros row: S2S_Z2_*)
+    static constexpr int C_BYTES = ATT32 ? C_ROWS * VS * 2 : 0;
     static constexpr int Q_WAVE_BYTES = NQ * 2 * 2 * 16 * 8 * 2;
     static constexpr int BYTES = K_BYTES + V_BYTES + C_BYTES + WAVES * Q_WAVE_BYTES;
 };
@@ -382,6 +390,9 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
         auto kb_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp2 + t * (h ? 0 : 32 * 8)); };
         h8 ka[NT], kb[NT], va[NT][2];
         f32x16 sc[NT];
+#if S2S_KB_SELECT
+        const h8 kconst = kb_of(0);                  // (upper lane half: the {1, 1, 0..} row; lower half: unused)
+#endif
         ka[0] = k_of(0); kb[0] = kb_of(0); ka[1] = k_of(1); kb[1] = kb_of(1);
         va[0][0] = v_of(0, 0); va[0][1] = v_of(0, 1);
         SBAR();
@@ -434,13 +445,22 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
             };
             auto P = [&](const unsigned (&x)[4]) { return __builtin_bit_cast(h8, (uv4{x[0], x[1], x[2], x[3]})); };
             // ---- vector instructions 0-1, K(t+2) reads, then the previous tile's last P.V MFMA
-            if (t + 2 < NT) ka[t + 2] = (S2S_ABL & (1 << 17)) ? opaque8(qb1) : k_of(t + 2);
+            if (t + 2 < NT) ka[t + 2] = (S2S_ABL & ((1 << 17) | (1 << 20))) ? opaque8(qb1) : k_of(t + 2);
             exps(0, 2);
             SBAR();
             if (t > 0) { O = MFMAW(va_prev1, P(pl_prev), O); }
             SBAR();
             exps(2, 8);
-            if (t + 2 < NT) kb[t + 2] = (S2S_ABL & (1 << 17)) ? opaque8(qb2) : kb_of(t + 2);
+#if S2S_KB_SELECT
+            // the second score MFMA's A operand is K_hi again in the lower lane half and a constant row in the upper one: built from
+            // ka and a register copy of that row by four v_cndmask instead of a second LDS read per tile
+            if (t + 2 < NT) {
+                const uv4 a_ = __builtin_bit_cast(uv4, ka[t + 2]), c_ = __builtin_bit_cast(uv4, kconst);
+                kb[t + 2] = __builtin_bit_cast(h8, (uv4{h ? c_[0] : a_[0], h ? c_[1] : a_[1], h ? c_[2] : a_[2], h ? c_[3] : a_[3]}));
+            }
+#else
+            if (t + 2 < NT) kb[t + 2] = (S2S_ABL & ((1 << 17) | (1 << 21))) ? opaque8(qb2) : kb_of(t + 2);
+#endif
             SBAR();
             if (t + 1 < NT) {
                 if (S2S_ABL & (1 << 18)) { f32x16 tmp_ = sc[0]; asm volatile("" : "+v"(tmp_)); sc[t + 1] = tmp_; }   // (timing only: no score MFMAs)
@@ -580,9 +600,15 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 template <class G> __device__ __forceinline__ void att32_consts(char* __restrict__ lds, const int tid, const int nthreads) {
     if constexpr (G::ATT32) {
         _Float16* cr = reinterpret_cast<_Float16*>(lds + G::K_BYTES + G::V_BYTES);
-        for (int i = tid; i < 3 * G::VS; i += nthreads)
-            cr[i] = (i < G::VS || (i >= 2 * G::VS && ((i - 2 * G::VS) & 7) < 2)) ? (_Float16)1.0f : (_Float16)0.0f;
+        for (int i = tid; i < G::C_ROWS * G::VS; i += nthreads)
+            cr[i] = (i < G::VS || (i >= 2 * G::VS && i < 3 * G::VS && ((i - 2 * G::VS) & 7) < 2)) ? (_Float16)1.0f : (_Float16)0.0f;
     }
+}
+
+// the second zeros row (see vp in fft_block_h): behind the small vectors and the progress counters, first byte on bank slot 4
+__device__ __forceinline__ const _Float16* zeros_row2(const float* sv_lds) {
+    const unsigned a = (unsigned)(size_t)(sv_lds + S2S_SV_FLOATS + S2S_PROG_INTS);          // (LDS addresses are 32-bit offsets)
+    return reinterpret_cast<const _Float16*>(sv_lds + S2S_SV_FLOATS + S2S_PROG_INTS) + (((4u * 16u - (a & 255u)) & 255u) >> 1);
 }
 
 // ---- wave balancing inside a SIMD (S2S_PRIO_MODE >= 4).  The two waves of a SIMD run the same attention loop, and the SIMD's
@@ -666,12 +692,12 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         f32x4 ak[NQ], av[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { ak[q] = bk; av[q] = f32x4{bv, bv, bv, bv}; }
-        mm_unit_h<NQ, LO>(ak, fa, xb);
+        if (!((S2S_ABL & (1 << 22)) && pf_src == nullptr)) mm_unit_h<NQ, LO>(ak, fa, xb);      // (1 << 22: timing without layer 0's Q/K/V MFMAs)
         SB_GEMM();
         if (!(S2S_ABL & 4096) || p == 3) load_unit_h<LO>(fa, ws);
         WS_ADVP(UF, 2048);                                   // Wk, pair p+1 (after the last pair: Wq, pair 0)
         SB_GEMM();
-        mm_unit_h_t<NQ, LO>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
+        if (!((S2S_ABL & (1 << 22)) && pf_src == nullptr)) mm_unit_h_t<NQ, LO>(av, fb, xb);                           // av[q]: rows = times 4g..4g+3 of the tile, column c = feature 16p + c
         const int head = 2 * p + (g >> 1), d0 = 4 * (g & 1);   // K accumulator rows 4g..4g+3 = head, d0..d0+3
         const int vrow = (2 * p + (c >> 3)) * 16 + (c & 7);    // V^T row of this lane's feature (hi; lo is 8 rows below)
 #pragma unroll
@@ -706,7 +732,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
 #ifndef S2S_PRIO_MODE
-#define S2S_PRIO_MODE 0      // experiments on the SIMD's wave arbitration during the attention loop
+#define S2S_PRIO_MODE 4      // 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); 0-3: experiments
 #endif
 #pragma unroll 1
     for (int u = 0; u < 2; ++u) {                     // two head pairs per iteration = one K = 32 block of fc
@@ -724,7 +750,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             f32x4 qa[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) qa[q] = bq;
-            if (pp == 0) mm_unit_h<NQ, LO>(qa, fa, xb); else mm_unit_h<NQ, LO>(qa, fb, xb);
+            if (!((S2S_ABL & (1 << 22)) && pf_src == nullptr)) { if (pp == 0) mm_unit_h<NQ, LO>(qa, fa, xb); else mm_unit_h<NQ, LO>(qa, fb, xb); }
             SB_GEMM();
             // Q^T rows live 4 per lane group; the S MFMA wants all 8 d of a head in every lane
             // ([Q_hi | Q_lo | Q_hi | Q_lo] over the lane groups): re-layout through the wave's scratch
@@ -740,6 +766,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                 // half of the wave's Q scratch into the pair-tile layout the fc operand wants (row 4g+r: head g >> 1, d = 4 (g & 1) + r)
                 const int hl = lane >> 5, n = lane & 31;
                 const _Float16* const crow = Vl + 8 * 16 * G::VS;         // [ones row][zeros row][{1, 1, 0..} row]
+                const _Float16* const zrow2 = zeros_row2(sv_lds);
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int head = 2 * p + hh;
@@ -749,7 +776,13 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     const h8 qb2 = *reinterpret_cast<const h8*>(hl ? crow + G::VS : qrow + 16 * 8);
                     const _Float16* kp = Kl + ((head * 2 + hl) * G::KEYS + n) * 8;                         // K_hi rows for h = 0, K_lo for h = 1
                     const _Float16* kp2 = hl ? crow + 2 * G::VS : kp;                                       // (second score MFMA: K_hi | {1, 1, 0..})
-                    const _Float16* vp = (n < 16 ? Vl + (head * 16 + n) * G::VS : n == 16 ? crow : crow + G::VS) + 8 * hl;
+                    // (rows 17-31 of the P.V operand are zeros.  A ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27} and
+                    // {4-11, 16-19, 28-31} of each lane half, and a V^T row r sits in 16-byte bank slot r mod 16: the zeros row the lanes of
+                    // the FIRST group read must not share a slot with rows 0-3 / 12-15, that of the second none with rows 4-11 or the
+                    // ones row -- two copies: one behind the small vectors, started on slot 4, and const row 1 (slot 1).  With a single zeros row in slot 1 lane 1's row
+                    // and the zeros row collided in every such read: 2 extra LDS cycles per read, about half of round 2's
+                    // SQ_LDS_BANK_CONFLICT count.)
+                    const _Float16* vp = (n < 16 ? Vl + (head * 16 + n) * G::VS : n == 16 ? crow : (n >= 20 && n < 28 && !S2S_ONE_ZEROS_ROW) ? zrow2 : crow + G::VS) + 8 * hl;
                     f32x16 O;
                     softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
                     float lsum = sum_h(O[8]);                              // row 16 lives in the lower lane half

@@ -434,7 +434,7 @@ template <int MODE> struct Fused {
     static constexpr int FNQ = (FMODE == 1) ? 2 : 1;              // chunks per frontend wave
     static constexpr int GROUP = DEC_WAVES * FNQ;
     static constexpr bool PF = (MODE == 1);                       // next chunk's slot prefetched into LDS (dec_blocks)
-    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS + S2S_PROG_INTS) * 4;   // + next slot, small vectors, progress counters
+    static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS + S2S_PROG_INTS + S2S_Z2_FLOATS) * 4;   // + next slot, small vectors, progress counters, 2nd zeros row
     static_assert(LDS <= 160 * 1024, "LDS per workgroup");
     static_assert(FMODE == 1 || DEC_WAVES * FrontLdsF32::BYTES <= LDS, "the f32 frontend waves' K/V images share the decoder's LDS");
 };
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
     const int nb = S2S_T_ENC + M.k - 1;
     if constexpr (MODE != 0) att32_consts<AttnLdsH<DEC_NQ, DEC_WAVES, DEC_NKT>>(lds_raw, threadIdx.x, DEC_WAVES * 64);   // (visible after the group loop's first barrier)
     if constexpr (MODE != 0) {                                     // the attention loop's progress counters (prio_balance)
-        if (threadIdx.x < S2S_PROG_INTS)
+        if (threadIdx.x < S2S_PROG_INTS + S2S_Z2_FLOATS)              // (and the second zeros row behind them)
             reinterpret_cast<int*>(lds_raw + DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS) * 4)[threadIdx.x] = 0;
     }
 #ifdef S2S_DIAG
