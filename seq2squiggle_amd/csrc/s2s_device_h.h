@@ -56,6 +56,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ATT32_MSLOT
 #define S2S_ATT32_MSLOT 1
 #endif
+#ifndef S2S_PRIO_MODE
+#define S2S_PRIO_MODE 4      // >= 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); + 2: also through
+#endif                       // the FFN slices; + 1: also through the K/V pairs (4..7); 0-3: experiments
 #ifndef S2S_ONE_ZEROS_ROW
 #define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
 #endif
@@ -681,6 +684,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     float bv_n = W[L.bv + c];                                  // V comes out transposed: this lane's column is one feature
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
+        if constexpr ((S2S_PRIO_MODE == 5 || S2S_PRIO_MODE == 7) && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS) + 8, wave);
         if (S2S_ABL & 4096) { for (int i = 0; i < 4; ++i) fb[i] = fa[i]; } else load_unit_h<LO>(fb, ws);   // (4096: timing without this phase's loads)
         WS_ADVP(UF, 2048);                                   // Wv, pair p
         const f32x4 bk = bk_n;
@@ -715,6 +719,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
         }
     }
+    if ((S2S_PRIO_MODE == 5 || S2S_PRIO_MODE == 7) && WAVES == 8) __builtin_amdgcn_s_setprio(0);
     DIAG_STAMP(1);
     if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // K/V of every wave visible (and the small vectors: svp() from here on)
     DIAG_STAMP(2);
@@ -731,9 +736,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     h8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
-#ifndef S2S_PRIO_MODE
-#define S2S_PRIO_MODE 4      // 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); 0-3: experiments
-#endif
 #pragma unroll 1
     for (int u = 0; u < 2; ++u) {                     // two head pairs per iteration = one K = 32 block of fc
         f32x4 opair[2][NQ];
@@ -965,6 +967,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     }
 #pragma unroll 1
     for (int hc = 0; hc < ((S2S_ABL & 128) ? 0 : 4); ++hc) {
+        if constexpr (S2S_PRIO_MODE >= 6 && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS) + 8, wave);
         f32x4 hid[NQ][4];
         f32x4 b1[4];
 #pragma unroll
@@ -1011,6 +1014,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
         }
     }
+    if (S2S_PRIO_MODE >= 6 && WAVES == 8) __builtin_amdgcn_s_setprio(0);
     DIAG_STAMP(5);
     layer_norm64<NQ, true>(X, svp(L.ln2g), svp(L.ln2b), g);
     DIAG_STAMP(6);
