@@ -64,11 +64,17 @@ def pmc_counters(mode, chunks_per_launch):
             chunks = c.get("_launch", {}).get("chunks", 32768)
             per_chunk = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / chunks
             cyc = c["GRBM_GUI_ACTIVE"] / 8
+            clock = None                       # in-kernel clock of the un-profiled diagnostic build (tools/diag_phases.py), same round
+            try:
+                clock = json.load(open(os.path.join(os.path.dirname(path), "diag_clock.json"))).get(mode)
+            except Exception:
+                pass
             return {"traffic": per_chunk * chunks_per_launch, "mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
-                    "valu_issue": 4 * c["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, "source": os.path.relpath(path, ROOT)}
+                    "valu_issue": 4 * c["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, "source": os.path.relpath(path, ROOT),
+                    "effective_clock_ghz": c.get("_effective_clock_ghz"), "in_kernel_clock": clock}
         except Exception:
             continue
-    return {"traffic": None, "mfma_busy": None, "valu_issue": None, "source": None}
+    return {"traffic": None, "mfma_busy": None, "valu_issue": None, "source": None, "effective_clock_ghz": None, "in_kernel_clock": None}
 
 
 def _e2e_dirs():
@@ -457,6 +463,9 @@ def main():
                 "frac": (tflops / peak) if tflops else None, "traffic": pmc["traffic"],
                 "traffic_unit": "bytes per launch (PMC, separate profiled run)", "traffic_source": pmc["source"],
                 "mfma_busy": pmc["mfma_busy"], "valu_issue": pmc["valu_issue"],
+                # the clock the chip held: GRBM_GUI_ACTIVE / 8 XCDs / kernel wall of the PMC pass (profiled runs clock lower), and the
+                # in-kernel s_memtime / s_memrealtime ratio of the un-profiled diagnostic build (cycles per chunk and CU beside it)
+                "effective_clock_ghz": pmc["effective_clock_ghz"], "in_kernel_clock": pmc["in_kernel_clock"],
                 "algorithmic_bytes_per_launch": 1088 * cpl if cpl else None,
                 "peak_note": {"f32": "f32-input MFMA peak (MI355X_MICROARCH.md)"}.get(
                     a.mode, "dense f16 MFMA peak (MI355X_MICROARCH.md); achieved counts ALGORITHMIC flops"),

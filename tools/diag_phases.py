@@ -44,6 +44,8 @@ if v[17]:
     ghz = v[16] / v[17] * 0.1
     print(f"kernel per wave: {v[16] / v[18]:.0f} shader cycles over {v[17] / v[18] * 10:.0f} ns -> the SIMDs ran at {ghz:.3f} GHz "
           f"({v[16] / v[18] / (bases.shape[0] / 256):.0f} cycles per chunk and CU)")
+    print("DIAGJSON " + __import__("json").dumps({"mode": sys.argv[1] if len(sys.argv) > 1 else "f16x3", "ghz": ghz,
+          "cycles_per_chunk_and_cu": v[16] / v[18] / (bases.shape[0] / 256), "chunks_per_launch": int(bases.shape[0])}))
     print("per wave of the workgroup (waves w and w+4 share SIMD w), cycles per chunk:")
     print("  wave   K/V    attention  att-done barrier  entry barrier   FFN   frontend")
     per = bases.shape[0] * LAUNCHES

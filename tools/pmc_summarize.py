@@ -23,5 +23,23 @@ for arg in sys.argv[1:]:
             k.setdefault("_launch", {"grid": int(row["Grid_Size"]), "workgroup": int(row["Workgroup_Size"]),
                                      "scratch_bytes_per_lane": int(row["Scratch_Size"]), "vgprs": int(row["VGPR_Count"]),
                                      "lds_bytes": int(row["LDS_Block_Size"]), **({"chunks": int(chunks)} if chunks else {})})
+    # wall time of that first dispatch in every pass (pmcN_kernel_trace.csv), so that a counter can be turned into a rate: the
+    # clock the chip held in the pass that counted GRBM_GUI_ACTIVE is GRBM_GUI_ACTIVE / 8 XCDs / that pass's duration
+    for path in sorted(glob.glob(os.path.join(d, "pmc*_kernel_trace.csv"))):
+        tag = os.path.basename(path).split("_")[0]
+        seen = set()
+        for row in csv.DictReader(open(path)):
+            name = row["Kernel_Name"].split("(")[0][:110]
+            if name in seen or name not in per:
+                continue
+            seen.add(name)
+            per[name].setdefault("_duration_ns", {})[tag] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    for name, k in per.items():
+        if "GRBM_GUI_ACTIVE" in k:
+            for path in sorted(glob.glob(os.path.join(d, "pmc*_counter_collection.csv"))):
+                tag = os.path.basename(path).split("_")[0]
+                if any(r["Counter_Name"] == "GRBM_GUI_ACTIVE" for r in csv.DictReader(open(path))) and tag in k.get("_duration_ns", {}):
+                    k["_effective_clock_ghz"] = k["GRBM_GUI_ACTIVE"] / 8 / k["_duration_ns"][tag]
+                    break
     out[mode] = per
 json.dump(out, sys.stdout, indent=1)

@@ -13,4 +13,18 @@ for m in f16x3 f32; do
 done
 cd $R && python3 bench.py > gpurun_out/$T/bench_f16x3.json 2> gpurun_out/$T/bench_f16x3.err
 python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32:65520 f16x3=gpurun_out/$T/pmc_f16x3:65520 > gpurun_out/$T/pmc_summary.json
+# the un-profiled diagnostic build: per-wave phase stamps + the clock the SIMDs held (s_memtime / s_memrealtime)
+S2S_DIAG_HEAT=3 python3 tools/diag_phases.py f16x3 > gpurun_out/$T/diag_phases.txt 2>&1
+S2S_DIAG_HEAT=2 python3 tools/diag_phases.py f32 > gpurun_out/$T/diag_phases_f32.txt 2>&1
+python3 - gpurun_out/$T <<'PY'
+import json, sys
+d = {}
+for f in ("diag_phases.txt", "diag_phases_f32.txt"):
+    for line in open(sys.argv[1] + "/" + f):
+        if line.startswith("DIAGJSON "):
+            j = json.loads(line[9:])
+            d[j["mode"]] = {"ghz": j["ghz"], "cycles_per_chunk_and_cu": j["cycles_per_chunk_and_cu"]}
+json.dump(d, open(sys.argv[1] + "/diag_clock.json", "w"))
+PY
+timeout -k 10 120 tools/probes/pass_probe > gpurun_out/$T/pass_probe.txt 2>&1
 ls gpurun_out/$T gpurun_out/$T/stats_f16x3
