@@ -59,6 +59,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_PRIO_MODE
 #define S2S_PRIO_MODE 4      // >= 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); + 2: also through
 #endif                       // the FFN slices; + 1: also through the K/V pairs (4..7); 0-3: experiments
+#ifndef S2S_KV_PIPE
+#define S2S_KV_PIPE 0          // 1: the K/V phase as a software pipeline (split + stores of pair p-1 behind the MFMAs of pair p)
+#endif
 #ifndef S2S_ONE_ZEROS_ROW
 #define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
 #endif
@@ -682,6 +685,87 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
     f32x4 bk_n = ldg4(W + L.bk_nat + 4 * g);
     float bv_n = W[L.bv + c];                                  // V comes out transposed: this lane's column is one feature
+#if S2S_KV_PIPE
+    if constexpr (NQ == 2 && LO && G::ATT32) {
+        // Software-pipelined K/V phase: the hi/lo split and the LDS stores of pair p-1 (40 vector / LDS instructions) are issued ONE
+        // PIECE BEHIND EACH MFMA of pair p (24 MFMAs, 16 pipe cycles each, 8 of them free for the issue port), in the order written
+        // (scheduling barriers between the groups); the last pair's pieces follow the loop.  Same operations per accumulator, same bits.
+        f32x4 pk[2], pv[2];                              // the previous pair's accumulators
+        int p_head = 0, p_d0 = 0, p_vrow = 0;
+        auto piece = [&](const int i, unsigned (&hi)[2], unsigned (&lo)[2]) {
+            // accumulator a = i >> 3 (K tile 0, K tile 1, V tile 0, V tile 1), piece i & 7 of its split + stores
+            const int a_ = i >> 3, s_ = i & 7, q = a_ & 1;
+            const f32x4 t = (a_ < 2) ? pk[q] : pv[q];
+            const int T = qt0 + q, key = 16 * T + c;
+            const int vcol = 16 * T + 8 * (g & 1) + 4 * (g >> 1);
+            _Float16* const dst_hi = (a_ < 2) ? Kl + ((p_head * 2 + 0) * G::KEYS + key) * 8 + p_d0 : Vl + p_vrow * G::VS + vcol;
+            _Float16* const dst_lo = (a_ < 2) ? Kl + ((p_head * 2 + 1) * G::KEYS + key) * 8 + p_d0 : Vl + (p_vrow + 8) * G::VS + vcol;
+            auto cvt = [&](const float x, const float y) {
+                unsigned hb = __builtin_bit_cast(unsigned, (h2v{(_Float16)x, (_Float16)y}));
+                asm("" : "+v"(hb));
+                return hb;
+            };
+            auto mix = [&](const float x, const float y, const unsigned hb) {
+                const h2v hv = __builtin_bit_cast(h2v, hb);
+                return __builtin_bit_cast(unsigned, (h2v{(_Float16)__builtin_fmaf(x, one, -(float)hv[0]), (_Float16)__builtin_fmaf(y, one, -(float)hv[1])}));
+            };
+            if (s_ == 0) hi[0] = cvt(t[0], t[1]);
+            else if (s_ == 1) hi[1] = cvt(t[2], t[3]);
+            else if (s_ == 2) lo[0] = mix(t[0], t[1], hi[0]);
+            else if (s_ == 3) *reinterpret_cast<uv2*>(dst_hi) = uv2{hi[0], hi[1]};
+            else if (s_ == 4) lo[1] = mix(t[2], t[3], hi[1]);
+            else if (s_ == 5) *reinterpret_cast<uv2*>(dst_lo) = uv2{lo[0], lo[1]};
+        };
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            unsigned hi_[2] = {0, 0}, lo_[2] = {0, 0};
+            auto behind = [&](const int m) {             // behind MFMA m (0..23) of this pair: piece m of the previous pair (6 per accumulator)
+                if (p > 0) piece((m / 6) * 8 + (m % 6), hi_, lo_);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            f32x4 ak[2], av[2];
+            if (p < 4) {
+                load_unit_h<LO>(fb, ws); WS_ADVP(UF, 2048);             // Wv, pair p
+                const f32x4 bk = bk_n;
+                const float bv = bv_n;
+                bk_n = ldg4(W + L.bk_nat + 16 * (p < 3 ? p + 1 : 3) + 4 * g);
+                bv_n = W[L.bv + 16 * (p < 3 ? p + 1 : 3) + c];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { ak[q] = bk; av[q] = f32x4{bv, bv, bv, bv}; }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const h8 wh = as_h8(fa[2 * kb]), wl = as_h8(fa[2 * kb + 1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { ak[q] = MFMAH(wh, xb[q][kb].hi, ak[q]); behind(6 * kb + q); }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { ak[q] = MFMAH(wh, xb[q][kb].lo, ak[q]); behind(6 * kb + 2 + q); }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { ak[q] = MFMAH(wl, xb[q][kb].hi, ak[q]); behind(6 * kb + 4 + q); }
+                }
+                load_unit_h<LO>(fa, ws); WS_ADVP(UF, 2048);             // Wk, pair p+1 (after the last pair: Wq, pair 0)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const h8 wh = as_h8(fb[2 * kb]), wl = as_h8(fb[2 * kb + 1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { av[q] = MFMAH(xb[q][kb].hi, wh, av[q]); behind(12 + 6 * kb + q); }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { av[q] = MFMAH(xb[q][kb].lo, wh, av[q]); behind(12 + 6 * kb + 2 + q); }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { av[q] = MFMAH(xb[q][kb].hi, wl, av[q]); behind(12 + 6 * kb + 4 + q); }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { pk[q] = ak[q]; pv[q] = av[q]; }
+                p_head = 2 * p + (g >> 1); p_d0 = 4 * (g & 1);
+                p_vrow = (2 * p + (c >> 3)) * 16 + (c & 7);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 24; ++m) behind(m);  // the last pair's pieces
+            }
+        }
+    } else
+#endif
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
         if constexpr ((S2S_PRIO_MODE == 5 || S2S_PRIO_MODE == 7) && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS) + 8, wave);
@@ -965,6 +1049,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;  // X = bias + residual accumulator
         }
     }
+#ifdef S2S_FFN_STAGGER          // experiment: the younger wave of each SIMD enters the FFN slices S2S_FFN_STAGGER x 64 cycles late
+    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_sleep(S2S_FFN_STAGGER);
+#endif
 #pragma unroll 1
     for (int hc = 0; hc < ((S2S_ABL & 128) ? 0 : 4); ++hc) {
         if constexpr (S2S_PRIO_MODE >= 6 && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS) + 8, wave);
