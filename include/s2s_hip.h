@@ -89,6 +89,10 @@ typedef struct s2s_debug {
     float* g;                  /* [B][16]      the dwell value before round() (modules.py:414-416/420-432) */
     float* y_scaled;           /* [B][250]     Decoder.forward output (modules.py:140-141) */
     float* z01;                /* [B][250]     the standard normals used for the noise term */
+    /* stage INPUTS (nullable): with these the launch serves as a stand-alone sub-module operator, the reference's
+     * NoiseSampler(x) / DurationSampler(x) on any emb_out and Decoder(x) on any [B,250,64] tensor (modules.py:275-278, 197-225, 133-142) */
+    const float* emb_in;       /* [B][16][64]  replaces the pre-net output: heads, dwell and encoder blocks run on it */
+    const float* dec_in;       /* [B][250][64] replaces the length-regulated + position-encoded decoder input */
 } s2s_debug;
 
 typedef struct s2s_handle s2s_handle;

@@ -21,7 +21,7 @@ class S2SParams(C.Structure):
 
 
 class S2SDebug(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("emb_out", "enc_out", "sigma", "conc", "rate", "g", "y_scaled", "z01")]
+    _fields_ = [(n, C.c_void_p) for n in ("emb_out", "enc_out", "sigma", "conc", "rate", "g", "y_scaled", "z01", "emb_in", "dec_in")]
 
 
 EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",

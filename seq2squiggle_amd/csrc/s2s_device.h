@@ -43,6 +43,7 @@ struct ParamsDev {
 struct DebugDev {
     float *emb_out, *enc_out, *sigma, *conc, *rate, *g, *y_scaled, *z01;
     unsigned long long* diag;       // S2S_DIAG builds only
+    const float *emb_in, *dec_in;   // stand-alone sub-module operators (TEST instance): stage INPUTS taken from memory
 };
 
 // ReLU as an integer max on the bit pattern (v_max_i32: negative floats have the sign bit set, i.e. are negative integers):

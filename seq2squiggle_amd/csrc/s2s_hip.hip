@@ -156,6 +156,17 @@ __device__ __forceinline__ void front_dwell(const FrontChunk (&io)[NQ], const Pa
     }
 }
 
+// stand-alone operators (TEST instance, dbg.emb_in): the pre-net output is replaced by rows the caller supplies
+template <int NQ>
+__device__ __forceinline__ void front_emb_in(const FrontChunk (&io)[NQ], const DebugDev& dbg, f32x4 (&X)[NQ][4], const int lane) {
+    if (!dbg.emb_in) return;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) X[q][ft] = ldg4(dbg.emb_in + (io[q].dbg_idx * 16 + c) * 64 + 16 * ft + 4 * g);
+}
+
 // X -> the chunks' hand-off slots (enc = true: enc_out) and, for the tests, the debug array of that stage (emb_out / enc_out)
 template <int NQ>
 __device__ __forceinline__ void front_store(const FrontChunk (&io)[NQ], const DebugDev& dbg, const f32x4 (&X)[NQ][4], const int lane,
@@ -195,6 +206,7 @@ __device__ __forceinline__ void frontend_f32(const ModelDev& M, const float* __r
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) X[0][mt] = Y[0][mt];
     }
+    front_emb_in<1>(io, dbg, X, lane);
     front_store<1>(io, dbg, X, lane, false);                // emb_out (debug only)
     float sig[1], cq[1] = {1.0f}, rq[1] = {1.0f};
     auto head = [&](const MlpOff m, float (&out)[1]) {
@@ -240,6 +252,7 @@ __device__ __forceinline__ void frontend_h16(const ModelDev& M, const float* __r
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) X[q][mt] = Y[q][mt];
     }
+    front_emb_in<NQ>(io, dbg, X, lane);
     front_store<NQ>(io, dbg, X, lane, false);                        // emb_out (debug only)
     FDIAG(1);
     {   // the three heads read emb_out only (modules.py:275-278, 197-225), so they run BEFORE the encoder blocks: emb_out is dead
@@ -349,6 +362,19 @@ __device__ __forceinline__ void dec_gather_finish(const GatherRaw& R, const int 
         for (int ft = 0; ft < 4; ++ft)
             X[q][ft] = real ? ((live ? R.e[q][ft] : f32x4{0, 0, 0, 0}) + R.pe[q][ft]) : f32x4{0, 0, 0, 0};
         sig_ext[q] = live ? R.sg[q] : 0.0f;
+    }
+}
+
+// stand-alone Decoder (TEST instance, dbg.dec_in): the chunk's decoder input comes from memory instead of the gather
+__device__ __forceinline__ void dec_override(const float* __restrict__ dec_in, const long long dbg_idx, const int wave, const int lane,
+                                             f32x4 (&X)[DEC_NQ][4]) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int q = 0; q < DEC_NQ; ++q) {
+        const int t = 16 * (DEC_NQ * wave + q) + c;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+            X[q][ft] = t < S2S_T_DEC ? ldg4(dec_in + (dbg_idx * S2S_T_DEC + t) * 64 + 16 * ft + 4 * g) : f32x4{0, 0, 0, 0};
     }
 }
 
@@ -511,6 +537,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
             GatherRaw R;
             dec_gather_issue(M, W, slot0, wave, lg, R);
             dec_gather_finish(R, wave, lg, X, sig_ext);
+            if (TEST && dbg.dec_in) dec_override(dbg.dec_in, dbg_base + g0, wave, lg, X);
         }
         DIAG_STAMP(8);
 #pragma unroll 1
@@ -536,6 +563,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
             dec_emit(M, ys, se, (unsigned long long)(first_chunk + b), P, inj_z01 ? inj_z01 + (size_t)b * S2S_T_DEC : nullptr,
                      out_signal + (size_t)b * S2S_T_DEC, dbg, dbg_base + b, wave, ln);
             dec_gather_finish(R, wave, ln, X, sig_ext);
+            if (TEST && dbg.dec_in) dec_override(dbg.dec_in, dbg_base + g0 + (j + 1 < n_here ? j + 1 : j), wave, ln, X);
             DIAG_STAMP(9);
         }
     }
@@ -1173,6 +1201,7 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
     if (dbg) {
         D.emb_out = dbg->emb_out; D.enc_out = dbg->enc_out; D.sigma = dbg->sigma; D.conc = dbg->conc;
         D.rate = dbg->rate; D.g = dbg->g; D.y_scaled = dbg->y_scaled; D.z01 = dbg->z01;
+        D.emb_in = dbg->emb_in; D.dec_in = dbg->dec_in;
     }
     D.diag = h->d_diag;
     const int nb = S2S_T_ENC + h->cfg.seq_kmer - 1;

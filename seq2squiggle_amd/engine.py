@@ -51,6 +51,8 @@ class Engine:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
         self.config = dict(config)
+        self._pe_dec_host = state_dict["decoders.position_enc"].detach().float().reshape(1, T_DEC, 64).clone()
+        self._pe_dec = None
         self.k = int(config["seq_kmer"])
         self.mode = mode
         ccfg = config_to_c(config, mode)
@@ -67,6 +69,12 @@ class Engine:
     def from_checkpoint(cls, path: str, device: Optional[int] = None, mode: str = "f16x3") -> "Engine":
         sd, cfg = load_checkpoint(path)
         return cls(sd, cfg, device, mode)
+
+    def decoder_position_enc(self) -> torch.Tensor:
+        """decoders.position_enc [1,250,64] on the engine's device (the stand-alone Decoder operator adds it, modules.py:136)."""
+        if self._pe_dec is None:
+            self._pe_dec = self._pe_dec_host.to(self.device)
+        return self._pe_dec
 
     def close(self):
         if self._h is not None:
@@ -91,9 +99,12 @@ class Engine:
                        first_global_chunk: int = 0, inject_g: Optional[torch.Tensor] = None,
                        inject_zdw: Optional[torch.Tensor] = None, inject_z01: Optional[torch.Tensor] = None,
                        debug: bool = False, out_signal: Optional[torch.Tensor] = None,
-                       out_dur: Optional[torch.Tensor] = None):
+                       out_dur: Optional[torch.Tensor] = None, emb_in: Optional[torch.Tensor] = None,
+                       dec_in: Optional[torch.Tensor] = None):
         """bases uint8 [B, 16+k-1] and n_valid uint8 [B] on the engine's device ->
-        dict(signal fp32 [B,250] pA, dur int32 [B,16] [, debug stage tensors])."""
+        dict(signal fp32 [B,250] pA, dur int32 [B,16] [, debug stage tensors]).
+        emb_in [B,16,64] / dec_in [B,250,64] (float32): stage inputs taken from these tensors instead of being computed from the
+        bases -- the stand-alone sub-module operators of seq2squiggle_amd.modules (s2s_debug.emb_in / dec_in)."""
         B = int(bases.shape[0])
         nb = T_ENC + self.k - 1
         if bases.dtype != torch.uint8 or bases.dim() != 2 or bases.shape[1] != nb or not bases.is_contiguous():
@@ -101,7 +112,8 @@ class Engine:
         if n_valid.dtype != torch.uint8 or n_valid.shape != (B,) or not n_valid.is_contiguous():
             raise ValueError("n_valid must be contiguous uint8 [B]")
         for name, t, shape in (("inject_g", inject_g, (B, T_ENC)), ("inject_zdw", inject_zdw, (B, T_ENC)),
-                               ("inject_z01", inject_z01, (B, T_DEC))):
+                               ("inject_z01", inject_z01, (B, T_DEC)), ("emb_in", emb_in, (B, T_ENC, 64)),
+                               ("dec_in", dec_in, (B, T_DEC, 64))):
             if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous()
                                   or t.device != self.device):
                 raise ValueError(f"{name} must be contiguous float32 {shape} on {self.device}")
@@ -122,6 +134,10 @@ class Engine:
                        g=torch.zeros(B, 16, **f), y_scaled=torch.zeros(B, T_DEC, **f), z01=torch.zeros(B, T_DEC, **f))
             dbg = _lib.S2SDebug(*[out[n].data_ptr() for n in ("emb_out", "enc_out", "sigma", "conc", "rate", "g",
                                                               "y_scaled", "z01")])
+        if emb_in is not None or dec_in is not None:
+            dbg = dbg or _lib.S2SDebug()
+            dbg.emb_in = None if emb_in is None else emb_in.data_ptr()
+            dbg.dec_in = None if dec_in is None else dec_in.data_ptr()
         p = params.to_c()
         with torch.cuda.device(self.device):
             rc = _lib.lib().s2s_predict_chunks(self._h, self._stream(), _ptr(bases), _ptr(n_valid),

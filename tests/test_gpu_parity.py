@@ -102,9 +102,52 @@ def test_submodule_call_surface(case):
     assert np.abs(y[..., 0].cpu().numpy() - g["y_scaled_gamma"]).max() < tol
     assert torch.allclose(dist.concentration.cpu(), torch.from_numpy(g["conc"]), rtol=3e-5, atol=3e-5)
     with pytest.raises(ValueError):
-        st.decoder(out + 1.0)                                                    # not the batch the previous stage produced
-    with pytest.raises(ValueError):
-        st.length_regulator(emb_out, enc_out, sigma, dwell_mean=9.0)
+        st.length_regulator(emb_out, enc_out, sigma, dwell_mean=9.0)             # contradicts the context's PredictParams
+
+
+def test_standalone_submodule_operators(case):
+    """The sub-modules as operators on ARBITRARY tensors, as a user of the reference may call them (modules.py: NoiseSampler
+    259-278, LengthRegulator 344-441, Decoder 97-142): random emb_out / x / sigma / decoder inputs that no encoder produced,
+    against the oracle's restatement of each module.  (The kernel's test instance takes the stage input from memory:
+    s2s_debug.emb_in / dec_in.)"""
+    from seq2squiggle_amd.modules import Stages
+    eng, dev, sd, cfg = case["eng"], case["dev"], case["sd"], case["cfg"]
+    gen = torch.Generator().manual_seed(11)
+    B = 37                                                           # not a multiple of the group of 16
+    emb = torch.rand(B, 16, 64, generator=gen) * 1.5                 # (emb_out is a ReLU output: non-negative)
+    x = torch.randn(B, 16, 64, generator=gen)
+    sig = torch.rand(B, 16, 1, generator=gen)
+    g_inj = torch.rand(B, 16, generator=gen) * 22
+    tol = 2e-5 if eng.mode == "f32" else 6e-5
+    st = Stages(eng, S.PredictParams(**P(noise_std=0.0)), inject_g=g_inj.to(dev))
+    # NoiseSampler on a foreign emb_out
+    got = st.noise_sampler(emb.to(dev))
+    assert got.shape == (B, 16, 1)
+    assert np.abs(got[..., 0].cpu().numpy() - O.noise_sampler(sd, emb).numpy()).max() < tol
+    # LengthRegulator on foreign tensors: Gamma parameters from emb, dwell from the injected draws, expansion of x and sigma
+    out, dur, dist, noise_ext, _ = st.length_regulator(emb.to(dev), x.to(dev), sig.to(dev), dwell_mean=12.5, dwell_std=0.0,
+                                                       duration_sampling=True, min_length=3)
+    conc, rate = O.duration_params(sd, emb)
+    ref_dur = O.durations(O.PredictParams(**P(noise_std=0.0)), B, g=g_inj)
+    ref_out, ref_sx = O.length_regulate(x, sig[..., 0], ref_dur)
+    assert np.array_equal(dur.cpu().numpy(), ref_dur.numpy().astype(np.float32))
+    assert torch.equal(out.cpu(), ref_out) and torch.equal(noise_ext[..., 0].cpu(), ref_sx)       # pure indexing: exact
+    assert torch.allclose(dist.concentration.cpu(), conc, rtol=3e-5, atol=3e-5) and torch.allclose(dist.rate.cpu(), rate, rtol=3e-5, atol=3e-5)
+    # Decoder on a foreign [B,250,64] (position_enc is added inside, modules.py:136)
+    h = torch.randn(B, 250, 64, generator=gen) * 0.7
+    y = st.decoder(h.to(dev))
+    ref_y = O.decoder(sd, cfg, h)
+    assert y.shape == (B, 250, 1)
+    assert np.array_equal(y[..., 0].cpu().numpy() == 0, ref_y.numpy() == 0) or np.abs(ref_y.numpy()[(y[..., 0].cpu().numpy() == 0) != (ref_y.numpy() == 0)]).max() < 1e-5
+    assert np.abs(y[..., 0].cpu().numpy() - ref_y.numpy()).max() < 3 * tol
+    # and chained use still continues the encoder's launch (the tensors of one fused launch, no second one)
+    codes = torch.from_numpy(case["g"]["codes"].astype(np.int64))
+    onehot = torch.zeros(*codes.shape, 5)
+    onehot[codes < 5] = torch.nn.functional.one_hot(codes[codes < 5], 5).float()
+    st2 = Stages(eng, S.PredictParams(**P(noise_std=0.0)), inject_g=dev_t(case, "g"))
+    enc_out, emb_out = st2.encoder(onehot.reshape(codes.shape[0], 16, -1).to(dev))
+    lr, _, _, _, _ = st2.length_regulator(emb_out, enc_out, st2.noise_sampler(emb_out))
+    assert st2.decoder(lr).data_ptr() == st2._ctx.out["y_scaled"].data_ptr()
 
 
 @pytest.mark.parametrize("key,over,use_g,use_z,use_zdw", CASES)
