@@ -108,3 +108,31 @@ def test_plain_c_consumer(tmp_path):
                     os.path.join(ROOT, "tests", "c", "cabi_check.c"), "-o", str(exe), "-ldl"], check=True)
     r = subprocess.run([str(exe), _lib._LIB_DEFAULT], capture_output=True, text=True)
     assert r.returncode == 0 and "CABI_OK 236804" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_pore_data_module_predict_loader():
+    """The reference's PoreDataModule(...).predict_dataloader() surface (dataloader.py:27-149): batches of predict_batch_size
+    chunks in read order, reads shorter than k dropped (dataloader.py:393-398), len() = total_l, and the reference's own fp16
+    one-hot batch format on request -- equal to the one-hot of the oracle's chunk codes (utils.py:56-89, 342-347)."""
+    import torch
+    from seq2squiggle_amd.dataloader import PoreDataModule
+    from seq2squiggle_amd import chunker
+    from oracle import s2s_oracle as O
+    rng = np.random.default_rng(2)
+    reads = [("".join(rng.choice(list("ACGTN"), int(n))), f"r{i}") for i, n in enumerate([5, 9, 40, 41, 300, 8, 77])]
+    cfg = {"seq_kmer": 9, "max_dna_len": 16}
+    dm = PoreDataModule(cfg, total_l=123, data_dir=reads, batch_size=7)
+    dm.setup("predict")
+    loader = dm.predict_dataloader()
+    assert len(loader) == 123 and len(loader.dataset) == 123
+    batches = list(loader)
+    want = [(name, chunker.encode_read(seq, 9)) for seq, name in reads]
+    ids = [i for b in batches for i in b[0]]
+    assert ids == [name for name, (b, nv) in want for _ in range(b.shape[0])] and "r0" not in ids and "r5" not in ids
+    assert all(len(b[0]) == 7 for b in batches[:-1]) and 0 < len(batches[-1][0]) <= 7
+    assert np.array_equal(torch.cat([b[1] for b in batches]).numpy(), np.concatenate([b for _, (b, nv) in want if b.shape[0]]))
+    hot = torch.cat([b[1] for b in PoreDataModule(cfg, 1, reads, batch_size=16, onehot=True).predict_dataloader()])
+    codes = np.concatenate([O.encode_read(seq, 9) for seq, _ in reads if len(seq) >= 9])
+    assert hot.dtype == torch.float16 and torch.equal(hot.float(), O.one_hot(codes).reshape(hot.shape))
+    with pytest.raises(NotImplementedError):
+        dm.setup("fit")
