@@ -378,6 +378,11 @@ def main():
                               "sum_of_ones": int(t.item())}))
         dist.destroy_process_group()
         return
+    # stdout carries ONE JSON line: everything else that writes to file descriptor 1 from here on (RCCL's version banner, library
+    # chatter) goes to stderr; the line itself is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     one_gpu = bool(os.environ.get("S2S_BENCH_ONE_GPU"))          # rehearsal on a 1-GPU box: every rank on cuda:0, barrier over gloo
     if one_gpu:
         local = 0
@@ -450,7 +455,7 @@ def main():
         small_rate = reps * small / (time.perf_counter() - t1)
 
     sharded = None
-    if dist and world > 1 and not a.no_cpu_baseline:
+    if dist and (world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST")) and not a.no_cpu_baseline:      # (the env var: the leg's RCCL calls on one GPU)
         sharded = end_to_end_sharded(a.mode, dist, rank, world, dev)
     if rank == 0:
         chunks_total = B * a.steps * world
@@ -508,7 +513,8 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             if a.mode == "f16x3":
                 out["reduced_precision"] = reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if dist:
         dist.destroy_process_group()
