@@ -5,6 +5,7 @@ engine's device and handed to the library as raw pointers; launches go to torch'
 stream so they order with the caller's other work.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -64,6 +65,8 @@ class Engine:
         if rc != 0:
             raise ValueError(f"s2s_create failed ({rc}): {L.s2s_last_error(None).decode()}")
         self._h = h
+        if os.environ.get("S2S_PROFILE_KERNEL"):          # diagnostic: HIP events around every predict launch, summed up at close()
+            self.set_profiling(True)
 
     @classmethod
     def from_checkpoint(cls, path: str, device: Optional[int] = None, mode: str = "f16x3") -> "Engine":
@@ -77,6 +80,10 @@ class Engine:
         return self._pe_dec
 
     def close(self):
+        if self._h is not None and os.environ.get("S2S_PROFILE_KERNEL"):
+            import sys
+            ms, nl, nc = self.kernel_ms()
+            print(f"[S2S_PROFILE_KERNEL] {nl} launches, {nc} chunks, {ms:.1f} ms of predict kernel", file=sys.stderr)
         if self._h is not None:
             _lib.lib().s2s_destroy(self._h)
             self._h = None

@@ -196,7 +196,9 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     rna = profile_name.startswith("rna")
     total = 0
     io = _io_executor()
-    pending = None            # the writer job of the previous super-batch
+    import collections
+    pending = collections.deque()   # writer jobs in flight on the (single) writer thread, oldest first: at most MAX_PENDING super-batches
+    MAX_PENDING = 3                 # of records wait there (~17 MB each), so a slow batch on the writer does not stall the next launch
     inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
     # copy_stream: D2H of finished super-batches; up_stream: H2D of the next one (its own stream: never queued behind a D2H that
     # waits for kernels)
@@ -276,7 +278,6 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         return names, buf_h, (R, head, row_read if gpu_rows else None), done
 
     def collect(job):
-        nonlocal pending
         ids, buf_h, (R, head, row_read), done = job
         mark("wait d2h")
         done.synchronize()
@@ -292,15 +293,15 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
         else:
             recs = writer.dac_records(ids, host[head: head + 2 * int(offs[-1])].view(np.int16), offs)
         mark("wait writer")
-        if pending is not None:
-            pending.result()
+        while pending and (pending[0].done() or len(pending) >= MAX_PENDING):
+            pending.popleft().result()              # (re-raises what the writer thread raised)
         mark("submit")
 
         def job_(recs=recs):
             mark("writer start")
             writer.write_records(recs)
             mark("writer end")
-        pending = io.submit(job_)
+        pending.append(io.submit(job_))
 
     try:
         mark("first read wanted")
@@ -311,8 +312,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             inflight = job
         if inflight is not None:
             collect(inflight)
-        if pending is not None:
-            pending.result()
+        while pending:
+            pending.popleft().result()
     finally:
         if hasattr(writer, "close"):               # POD5: run-info and reads tables, footer (on the writer thread as well)
             io.submit(writer.close).result()
