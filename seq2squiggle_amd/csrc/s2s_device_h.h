@@ -1077,11 +1077,15 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hid[q][mt][r] = relu1(t[q][r]);
+                for (int r = 0; r < 4; ++r) hid[q][mt][r] = (S2S_ABL & (1 << 23)) ? t[q][r] : relu1(t[q][r]);      // (1 << 23: timing without the FFN's relu / split VALU work)
         }
         HL hb[NQ][2];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { hb[q][0] = split8<LO>(hid[q][0], hid[q][1], one); hb[q][1] = split8<LO>(hid[q][2], hid[q][3], one); }
+        for (int q = 0; q < NQ; ++q) {
+            if (S2S_ABL & (1 << 23)) {
+                hb[q][0].hi = as_h8(hid[q][0]); hb[q][0].lo = as_h8(hid[q][1]); hb[q][1].hi = as_h8(hid[q][2]); hb[q][1].lo = as_h8(hid[q][3]);
+            } else { hb[q][0] = split8<LO>(hid[q][0], hid[q][1], one); hb[q][1] = split8<LO>(hid[q][2], hid[q][3], one); }
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {              // W2 units: rows 16mt .., columns 64hc ..
             f32x4 t[NQ];
