@@ -51,3 +51,38 @@ def test_shards_partition_the_reads_and_number_the_chunks(lens, world, k):
         lo, hi, first = sh[r]
         assert lo <= hi and (r == 0 or sh[r - 1][1] == lo)
         assert first == sum(chunks[:lo])                  # global chunk index keys the RNG: independent of the split
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(1, 2 ** 31 - 1), r=st.integers(40, 4000), n=st.integers(1, 120),
+       contigs=st.lists(st.integers(200, 6000), min_size=1, max_size=4), n_density=st.sampled_from([0.0, 0.01, 0.08, 0.3]),
+       profile=st.sampled_from(["dna-r10-prom", "dna-r9-min", "rna-004-min"]), min_len=st.sampled_from([30, 150]),
+       stop=st.integers(0, 40))
+def test_native_sampler_replay_property(seed, r, n, contigs, n_density, profile, min_len, stop):
+    """s2s_sampler_replay (the rank skip-ahead) walks exactly the draws of the reference sampler (utils.py:415-479) for arbitrary
+    genomes, N densities, read lengths and profiles: same accepted lengths, same next read index, same `random` state -- whole,
+    and stopped after `stop` accepted reads."""
+    import random
+    from seq2squiggle_amd import utils as U
+    rng = np.random.default_rng(seed % 100003)
+    seqs = []
+    for L in contigs:
+        s = rng.choice(list("ACGT"), L)
+        s[rng.random(L) < n_density] = "N"
+        seqs.append("".join(s))
+    lens = [len(s) for s in seqs]
+    total = sum(lens)
+    seed = seed % (2 ** 31)                                           # inside the scipy fast range for any n
+    random.seed(seed)
+    want = U.sampling(n, seqs, lens, r, seed, total, "expon", profile, min_len, materialise=(0, 0))
+    end_state = random.getstate()
+    random.seed(seed)
+    got = U.replay_sampler(n, seqs, lens, r, seed, total, "expon", profile, min_len)
+    assert got is not None and got[0].tolist() == want and got[1] == n and random.getstate() == end_state
+    k = min(stop, len(want))
+    random.seed(seed)
+    part = U.replay_sampler(n, seqs, lens, r, seed, total, "expon", profile, min_len, stop_after=k)
+    assert part[0].tolist() == want[:k]
+    rest = list(U.sampling_iter(n, seqs, lens, r, seed, total, "expon", profile, min_len, first_read_i=part[1], n_accepted=k,
+                                materialise=(0, 0)))
+    assert rest == want[k:] and random.getstate() == end_state
