@@ -34,7 +34,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #endif
 #define S2S_PF_FLOATS (1024 + 16 + 16)   // one frontend -> decoder hand-off slot (s2s_hip.hip: S2S_SLOT_FLOATS)
 #define S2S_Z2_FLOATS (256 + 64)         // a second all-zeros V^T row (264 halves) + room to start it on 16-byte bank slot 4: see vp in fft_block_h
-#define S2S_PROG_INTS 16                 // per-wave progress counters of the attention loop (S2S_PRIO_MODE 4 / 5), behind the small vectors
+#define S2S_PROG_INTS 16                 // per-wave progress counters of the attention loop (prio_balance), behind the small vectors
 #define S2S_SV_FLOATS 960                // bq_nat, bk_nat, bq, bk, bv, bfc (64 each), b1 (256), b2, ln1g, ln1b, ln2g, ln2b (64 each)
 #define WS_ADVP(n, bit) (ws += ((S2S_ABL & (bit)) ? 0 : (n)))   // timing ablation: this phase's unit loads hit the same (L1-hot) lines
 // Scheduling barriers pin the weight-unit / K,V-fragment loads in front of the MFMAs they are prefetched behind; the
@@ -57,19 +57,10 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define S2S_ATT32_MSLOT 1
 #endif
 #ifndef S2S_PRIO_MODE
-#define S2S_PRIO_MODE 4      // >= 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); + 2: also through
-#endif                       // the FFN slices; + 1: also through the K/V pairs (4..7); 0-3: experiments
-#ifndef S2S_KV_PIPE
-#define S2S_KV_PIPE 0          // 1: the K/V phase as a software pipeline (split + stores of pair p-1 behind the MFMAs of pair p)
+#define S2S_PRIO_MODE 4      // 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); 0: off (A/B builds)
 #endif
 #ifndef S2S_ONE_ZEROS_ROW
 #define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
-#endif
-#ifndef S2S_KB_SELECT
-#define S2S_KB_SELECT 0
-#endif
-#ifndef S2S_ATT_PIPE
-#define S2S_ATT_PIPE 0          // > 0: the tile-pipelined fast softmax path (softmax_pv32), value = vector instructions per MFMA in its pattern
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMAW(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -351,8 +342,6 @@ __device__ __forceinline__ float sum_h(float v) {
     auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
-__device__ __forceinline__ h8 opaque8(h8 x) { asm volatile("" : "+v"(x)); return x; }   // (timing ablations: a value the optimiser cannot see through)
-__device__ __forceinline__ h8 P_last(const unsigned (&x)[4]) { return __builtin_bit_cast(h8, (uv4{x[0], x[1], x[2], x[3]})); }
 template <int TV, bool SAFE, bool LO>
 __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
                                              const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
@@ -381,130 +370,6 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     };
     f32x16 negm = zero16;
     h8 qb2m = qb2;
-#if S2S_ATT_PIPE
-    if constexpr (!SAFE && LO) {
-        // Software-pipelined fast path, one 32-key tile per stage, IN THE ORDER WRITTEN: every group of statements below is fenced by
-        // a scheduling barrier, so hipcc only allocates registers and inserts the hazard wait states.  While tile t's 16 scores per
-        // lane go through v_exp / v_cvt_pk / v_fma_mix and its four P.V MFMAs, the two score MFMAs of tile t+1 are in flight and
-        // the LDS reads of tile t+2's K rows and tile t+1's V rows have been issued.  The six MFMAs of a stage sit 6-9 vector
-        // instructions apart: never two back to back (a wave that waits for the matrix pipe at the issue port also stops the other
-        // wave of its SIMD), and a lone wave never waits for an LDS round trip or a score chain in front of its exponentials.
-        // tools/probes/pass_probe.hip measured this order against the one hipcc picks for the two-tile pass below: 1470 against
-        // 1774 cycles per 64 keys with two waves per SIMD, 816 against 1116 for a lone wave.  Same operations in the same order
-        // per accumulator as the pass below, hence the same bits.
-#define SBAR() __builtin_amdgcn_sched_barrier(0)
-        auto kb_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp2 + t * (h ? 0 : 32 * 8)); };
-        h8 ka[NT], kb[NT], va[NT][2];
-        f32x16 sc[NT];
-#if S2S_KB_SELECT
-        const h8 kconst = kb_of(0);                  // (upper lane half: the {1, 1, 0..} row; lower half: unused)
-#endif
-        ka[0] = k_of(0); kb[0] = kb_of(0); ka[1] = k_of(1); kb[1] = kb_of(1);
-        va[0][0] = v_of(0, 0); va[0][1] = v_of(0, 1);
-        SBAR();
-        {   // raw scores of the first 64 keys -> the shift (column max + head-room), riding in the second score MFMA from here on
-            f32x16 r0 = MFMAW(ka[0], qb1, zero16);
-            f32x16 r1 = MFMAW(ka[1], qb1, zero16);
-            r0 = MFMAW(kb[0], qb2, r0);
-            r1 = MFMAW(kb[1], qb2, r1);
-            SBAR();
-            float mh = r0[0];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mh = fmaxf(mh, fmaxf(r0[r], r1[r]));
-            const float nm = -(max_h(mh) + S2S_SHIFT_BIAS);
-            const _Float16 nh = (_Float16)nm;
-            const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, (_Float16)(nm - (float)nh)}));
-            uv4 q2 = __builtin_bit_cast(uv4, qb2);
-            q2[0] = h ? pk : q2[0];
-            qb2m = __builtin_bit_cast(h8, q2);
-        }
-        SBAR();
-        sc[0] = MFMAW(kb[0], qb2m, MFMAW(ka[0], qb1, zero16));
-        SBAR();
-        unsigned ph[2][4], pl[2][4];                 // the P operands of the current tile: [16-key step][4 packed pairs]
-        h8 va_prev1 = va[0][1];
-        unsigned pl_prev[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t == NT - 1) mask_last(sc[t]);
-            float e[16];
-            auto exps = [&](const int lo_, const int hi_) {
-#pragma unroll
-                for (int i = lo_; i < hi_; ++i) e[i] = __builtin_amdgcn_exp2f(sc[t][i]);
-            };
-            auto cvts = [&](const int st) {          // v_cvt_pk_f16_f32 x4: the hi halves of 8 probabilities
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned hb = __builtin_bit_cast(unsigned, (h2v{(_Float16)e[8 * st + 2 * j], (_Float16)e[8 * st + 2 * j + 1]}));
-                    asm("" : "+v"(hb));
-                    ph[st][j] = hb;
-                }
-            };
-            auto mixes = [&](const int st, const int j0, const int j1) {     // v_fma_mixlo / mixhi: the lo halves (see split2)
-#pragma unroll
-                for (int j = j0; j < j1; ++j) {
-                    const h2v hv = __builtin_bit_cast(h2v, ph[st][j]);
-                    const h2v l = {(_Float16)__builtin_fmaf(e[8 * st + 2 * j], one, -(float)hv[0]),
-                                   (_Float16)__builtin_fmaf(e[8 * st + 2 * j + 1], one, -(float)hv[1])};
-                    pl[st][j] = __builtin_bit_cast(unsigned, l);
-                }
-            };
-            auto P = [&](const unsigned (&x)[4]) { return __builtin_bit_cast(h8, (uv4{x[0], x[1], x[2], x[3]})); };
-            // ---- vector instructions 0-1, K(t+2) reads, then the previous tile's last P.V MFMA
-            if (t + 2 < NT) ka[t + 2] = (S2S_ABL & ((1 << 17) | (1 << 20))) ? opaque8(qb1) : k_of(t + 2);
-            exps(0, 2);
-            SBAR();
-            if (t > 0) { O = MFMAW(va_prev1, P(pl_prev), O); }
-            SBAR();
-            exps(2, 8);
-#if S2S_KB_SELECT
-            // the second score MFMA's A operand is K_hi again in the lower lane half and a constant row in the upper one: built from
-            // ka and a register copy of that row by four v_cndmask instead of a second LDS read per tile
-            if (t + 2 < NT) {
-                const uv4 a_ = __builtin_bit_cast(uv4, ka[t + 2]), c_ = __builtin_bit_cast(uv4, kconst);
-                kb[t + 2] = __builtin_bit_cast(h8, (uv4{h ? c_[0] : a_[0], h ? c_[1] : a_[1], h ? c_[2] : a_[2], h ? c_[3] : a_[3]}));
-            }
-#else
-            if (t + 2 < NT) kb[t + 2] = (S2S_ABL & ((1 << 17) | (1 << 21))) ? opaque8(qb2) : kb_of(t + 2);
-#endif
-            SBAR();
-            if (t + 1 < NT) {
-                if (S2S_ABL & (1 << 18)) { f32x16 tmp_ = sc[0]; asm volatile("" : "+v"(tmp_)); sc[t + 1] = tmp_; }   // (timing only: no score MFMAs)
-                else sc[t + 1] = MFMAW(ka[t + 1], qb1, zero16);                  // score MFMA 1 of the next tile
-            }
-            SBAR();
-            cvts(0);
-            mixes(0, 0, 1);
-            SBAR();
-            if (t + 1 < NT && !(S2S_ABL & (1 << 18))) sc[t + 1] = MFMAW(kb[t + 1], qb2m, sc[t + 1]);   // score MFMA 2
-            SBAR();
-            mixes(0, 1, 4);
-            exps(8, 9);
-            SBAR();
-            O = MFMAW(va[t][0], P(ph[0]), O);
-            SBAR();
-            exps(9, 16);
-            if (t + 1 < NT) va[t + 1][0] = (S2S_ABL & (1 << 19)) ? opaque8(qb1) : v_of(t + 1, 0);
-            cvts(1);
-            // (two of the four)
-            SBAR();
-            O = MFMAW(va[t][0], P(pl[0]), O);
-            SBAR();
-            mixes(1, 0, 2);
-            if (t + 1 < NT) va[t + 1][1] = (S2S_ABL & (1 << 19)) ? opaque8(qb2) : v_of(t + 1, 1);
-            SBAR();
-            O = MFMAW(va[t][1], P(ph[1]), O);
-            SBAR();
-            mixes(1, 2, 4);
-            SBAR();
-            va_prev1 = va[t][1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pl_prev[j] = pl[1][j];
-        }
-        O = MFMAW(va_prev1, P_last(pl_prev), O);
-#undef SBAR
-    } else
-#endif
     if constexpr (!SAFE) {
         // fast path: the shift is pass 0's column max (+ head-room), later passes compute no max at all.  Two tiles (64 keys) per
         // pass, as straight-line code.  (Measured: issuing tile t+1's score MFMAs ahead of tile t's exponentials by hand -- no
@@ -685,90 +550,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     // ---- K^T and V^T of this wave's time tiles, all heads -> LDS as hi/lo halves (layers.py:74-78)
     f32x4 bk_n = ldg4(W + L.bk_nat + 4 * g);
     float bv_n = W[L.bv + c];                                  // V comes out transposed: this lane's column is one feature
-#if S2S_KV_PIPE
-    if constexpr (NQ == 2 && LO && G::ATT32) {
-        // Software-pipelined K/V phase: the hi/lo split and the LDS stores of pair p-1 (40 vector / LDS instructions) are issued ONE
-        // PIECE BEHIND EACH MFMA of pair p (24 MFMAs, 16 pipe cycles each, 8 of them free for the issue port), in the order written
-        // (scheduling barriers between the groups); the last pair's pieces follow the loop.  Same operations per accumulator, same bits.
-        f32x4 pk[2], pv[2];                              // the previous pair's accumulators
-        int p_head = 0, p_d0 = 0, p_vrow = 0;
-        auto piece = [&](const int i, unsigned (&hi)[2], unsigned (&lo)[2]) {
-            // accumulator a = i >> 3 (K tile 0, K tile 1, V tile 0, V tile 1), piece i & 7 of its split + stores
-            const int a_ = i >> 3, s_ = i & 7, q = a_ & 1;
-            const f32x4 t = (a_ < 2) ? pk[q] : pv[q];
-            const int T = qt0 + q, key = 16 * T + c;
-            const int vcol = 16 * T + 8 * (g & 1) + 4 * (g >> 1);
-            _Float16* const dst_hi = (a_ < 2) ? Kl + ((p_head * 2 + 0) * G::KEYS + key) * 8 + p_d0 : Vl + p_vrow * G::VS + vcol;
-            _Float16* const dst_lo = (a_ < 2) ? Kl + ((p_head * 2 + 1) * G::KEYS + key) * 8 + p_d0 : Vl + (p_vrow + 8) * G::VS + vcol;
-            auto cvt = [&](const float x, const float y) {
-                unsigned hb = __builtin_bit_cast(unsigned, (h2v{(_Float16)x, (_Float16)y}));
-                asm("" : "+v"(hb));
-                return hb;
-            };
-            auto mix = [&](const float x, const float y, const unsigned hb) {
-                const h2v hv = __builtin_bit_cast(h2v, hb);
-                return __builtin_bit_cast(unsigned, (h2v{(_Float16)__builtin_fmaf(x, one, -(float)hv[0]), (_Float16)__builtin_fmaf(y, one, -(float)hv[1])}));
-            };
-            if (s_ == 0) hi[0] = cvt(t[0], t[1]);
-            else if (s_ == 1) hi[1] = cvt(t[2], t[3]);
-            else if (s_ == 2) lo[0] = mix(t[0], t[1], hi[0]);
-            else if (s_ == 3) *reinterpret_cast<uv2*>(dst_hi) = uv2{hi[0], hi[1]};
-            else if (s_ == 4) lo[1] = mix(t[2], t[3], hi[1]);
-            else if (s_ == 5) *reinterpret_cast<uv2*>(dst_lo) = uv2{lo[0], lo[1]};
-        };
-#pragma unroll
-        for (int p = 0; p < 5; ++p) {
-            unsigned hi_[2] = {0, 0}, lo_[2] = {0, 0};
-            auto behind = [&](const int m) {             // behind MFMA m (0..23) of this pair: piece m of the previous pair (6 per accumulator)
-                if (p > 0) piece((m / 6) * 8 + (m % 6), hi_, lo_);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            f32x4 ak[2], av[2];
-            if (p < 4) {
-                load_unit_h<LO>(fb, ws); WS_ADVP(UF, 2048);             // Wv, pair p
-                const f32x4 bk = bk_n;
-                const float bv = bv_n;
-                bk_n = ldg4(W + L.bk_nat + 16 * (p < 3 ? p + 1 : 3) + 4 * g);
-                bv_n = W[L.bv + 16 * (p < 3 ? p + 1 : 3) + c];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { ak[q] = bk; av[q] = f32x4{bv, bv, bv, bv}; }
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const h8 wh = as_h8(fa[2 * kb]), wl = as_h8(fa[2 * kb + 1]);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { ak[q] = MFMAH(wh, xb[q][kb].hi, ak[q]); behind(6 * kb + q); }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { ak[q] = MFMAH(wh, xb[q][kb].lo, ak[q]); behind(6 * kb + 2 + q); }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { ak[q] = MFMAH(wl, xb[q][kb].hi, ak[q]); behind(6 * kb + 4 + q); }
-                }
-                load_unit_h<LO>(fa, ws); WS_ADVP(UF, 2048);             // Wk, pair p+1 (after the last pair: Wq, pair 0)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const h8 wh = as_h8(fb[2 * kb]), wl = as_h8(fb[2 * kb + 1]);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { av[q] = MFMAH(xb[q][kb].hi, wh, av[q]); behind(12 + 6 * kb + q); }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { av[q] = MFMAH(xb[q][kb].lo, wh, av[q]); behind(12 + 6 * kb + 2 + q); }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { av[q] = MFMAH(xb[q][kb].hi, wl, av[q]); behind(12 + 6 * kb + 4 + q); }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { pk[q] = ak[q]; pv[q] = av[q]; }
-                p_head = 2 * p + (g >> 1); p_d0 = 4 * (g & 1);
-                p_vrow = (2 * p + (c >> 3)) * 16 + (c & 7);
-            } else {
-#pragma unroll
-                for (int m = 0; m < 24; ++m) behind(m);  // the last pair's pieces
-            }
-        }
-    } else
-#endif
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
-        if constexpr ((S2S_PRIO_MODE == 5 || S2S_PRIO_MODE == 7) && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS) + 8, wave);
         if (S2S_ABL & 4096) { for (int i = 0; i < 4; ++i) fb[i] = fa[i]; } else load_unit_h<LO>(fb, ws);   // (4096: timing without this phase's loads)
         WS_ADVP(UF, 2048);                                   // Wv, pair p
         const f32x4 bk = bk_n;
@@ -803,7 +586,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
         }
     }
-    if ((S2S_PRIO_MODE == 5 || S2S_PRIO_MODE == 7) && WAVES == 8) __builtin_amdgcn_s_setprio(0);
     DIAG_STAMP(1);
     if (!(S2S_ABL & 4)) block_sync<WAVES == 1>();     // K/V of every wave visible (and the small vectors: svp() from here on)
     DIAG_STAMP(2);
@@ -823,12 +605,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll 1
     for (int u = 0; u < 2; ++u) {                     // two head pairs per iteration = one K = 32 block of fc
         f32x4 opair[2][NQ];
-        if (S2S_PRIO_MODE == 1 && WAVES == 8) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); }
-        if (S2S_PRIO_MODE == 2 && WAVES == 8) { if ((wave >= 4) == (u == 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int p = 2 * u + pp;
-            if (S2S_PRIO_MODE == 3 && WAVES == 8) { if ((wave >= 4) == (pp == 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             // weight units of this iteration: Wq(2u) [fa], Wq(2u+1) [fb], Wfc(u) m-tiles 0-1 [fa], 2-3 [fb]
             if (pp == 0) { load_unit_h<LO>(fb, ws); WS_ADVP(UF, 8192); } else { load_unit_h<LO>(fa, ws); WS_ADVP(UF, 8192); }
             const f32x4 bq = ldg4(svp(L.bq_nat) + 16 * p + 4 * g);   // (pack_layer: Wq and bq of the f16 streams carry the log2(e)/sqrt(d_k) factor)
@@ -1049,12 +828,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) X[q][mt] = acc[q][mt] + b;  // X = bias + residual accumulator
         }
     }
-#ifdef S2S_FFN_STAGGER          // experiment: the younger wave of each SIMD enters the FFN slices S2S_FFN_STAGGER x 64 cycles late
-    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_sleep(S2S_FFN_STAGGER);
-#endif
 #pragma unroll 1
     for (int hc = 0; hc < ((S2S_ABL & 128) ? 0 : 4); ++hc) {
-        if constexpr (S2S_PRIO_MODE >= 6 && WAVES == 8) prio_balance(reinterpret_cast<int*>(sv_lds + S2S_SV_FLOATS) + 8, wave);
         f32x4 hid[NQ][4];
         f32x4 b1[4];
 #pragma unroll
@@ -1105,7 +880,6 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             for (int q = 0; q < NQ; ++q) X[q][mt] = t[q];
         }
     }
-    if (S2S_PRIO_MODE >= 6 && WAVES == 8) __builtin_amdgcn_s_setprio(0);
     DIAG_STAMP(5);
     layer_norm64<NQ, true>(X, svp(L.ln2g), svp(L.ln2b), g);
     DIAG_STAMP(6);
