@@ -81,12 +81,20 @@ def version():
 @click.option("-v", "--verbosity", type=click.Choice(["debug", "info", "warning", "error"], case_sensitive=False), default="info")
 @click.option("--compute-mode", default="f16x3", type=click.Choice(["f16x3", "f32", "f16"]), hidden=True,
               help="Decoder arithmetic of the MI355X engine.")
+@click.option("--gpus", default=1, type=int, hidden=True,
+              help="Run on this many GPUs of the node: one process per GPU, the read set sharded, one OUT.rankN file per process "
+                   "(the same as starting the command under torchrun --nproc-per-node N).")
 @click.pass_context
 def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profile, show_advanced_options, noise_sampler,
             duration_sampler, dwell_mean, dwell_std, noise_std, distr, predict_batch_size, export_every_n_samples,
             sample_rate, bps, digitisation, range_val, offset_mean, offset_std, median_before_mean, median_before_std,
-            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode):
+            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode, gpus):
     """Generate nanopore signals from a reference genome (default) or from reads (--read-input)."""
+    import os
+    if gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # The reference leaves multi-GPU runs to Lightning (devices="auto", DDP: inference.py:430-445); here the command starts its
+        # own ranks as CHILD processes -- before anything in this process has touched the GPU -- and returns their exit code.
+        ctx.exit(_launch_ranks(gpus))
     from .inference import inference_run
     from .utils import set_seeds, setup_logging
 
@@ -112,6 +120,48 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
                   median_before_std=median_before_std, min_noise=min_noise, min_duration=min_duration,
                   min_read_len=min_read_len, preserve_read_ids=preserve_read_ids, seed=seed, mode=compute_mode)
     logger.info("Prediction finished.")
+
+
+def _launch_ranks(gpus: int) -> int:
+    """`predict --gpus N` outside torchrun: the same command line under torch.distributed.run, one rank per GPU (rendezvous on
+    127.0.0.1); S2S_DRY_LAUNCH=1 prints the child command instead of running it."""
+    import json
+    import os
+    import socket
+    import subprocess
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        argv.append(a)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "seq2squiggle_amd"] + argv
+    if os.environ.get("S2S_DRY_LAUNCH"):
+        click.echo(json.dumps({"dry_launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+@main.command("merge-shards")
+@click.argument("shards", nargs=-1, required=True, type=click.Path(exists=True, dir_okay=False))
+@click.option("-o", "--out", required=True, type=click.Path(dir_okay=False), help="Merged .blow5 / .slow5 file.")
+def merge_shards(shards, out):
+    """Concatenate the OUT.rankN.blow5 (or .slow5) shard files of a multi-GPU run, in the order given, into one file.
+    (Read ids and read numbers already continue across the shards of one run.)"""
+    from .signal_io import merge_shards as _merge
+    n = _merge(list(shards), out)
+    click.echo(f"{n} records -> {out}")
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import torch
 
 from .chunker import encode_read, n_chunks as _n_chunks, pack_reads
 from .model import seq2squiggle
-from .parallel import rank_output_path, rank_world, shard_reads
+from .parallel import local_device, rank_output_path, rank_world, shard_reads
 from .signal_io import BLOW5Writer, POD5Writer
 from .utils import get_profile, get_reads, update_config, update_profile
 
@@ -338,7 +338,8 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     config = update_config(profile, config)
     ideal_mode = not (duration_sampling or dwell_std > 0)
 
-    rank, local_rank, world = rank_world()
+    rank, _, world = rank_world()
+    local_rank = local_device()
     writer, export_every_n_samples = get_writer(rank_output_path(str(out), rank, world), profile_dict, ideal_mode,
                                                 export_every_n_samples, profile_name=profile,
                                                 preserve_read_ids=preserve_read_ids)

@@ -14,6 +14,12 @@ def rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def local_device() -> int:
+    """The GPU of this rank: LOCAL_RANK (one process per GPU).  S2S_ONE_GPU=1 puts every rank on GPU 0 -- a rehearsal of the
+    multi-process path on a one-GPU box (the ranks then share the device; there is no data-path collective to object)."""
+    return 0 if os.environ.get("S2S_ONE_GPU") else rank_world()[1]
+
+
 def shard_reads(read_lens: Sequence[int], k: int, world: int) -> List[Tuple[int, int, int]]:
     """-> per rank (first_read, end_read, first_global_chunk): contiguous read ranges whose chunk counts are as
     equal as a prefix split allows."""

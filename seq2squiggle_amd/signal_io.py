@@ -418,6 +418,74 @@ def iter_blow5(path):
                "median_before": mb, "read_number": rn, "start_mux": mux, "start_time": st_}
 
 
+def merge_shards(paths, out: str) -> int:
+    """Concatenate BLOW5 (or SLOW5 ASCII) shard files with identical headers -- the out.rankN files of a sharded run
+    (parallel.rank_output_path) -- into `out`: header of the first shard, every shard's records in order, one end-of-file marker.
+    Streams; nothing is decompressed.  -> number of records.  Header attributes that differ between shards (only the wall-clock
+    exp_start_time may) are taken from the first."""
+    import shutil
+    if not paths:
+        raise ValueError("no shard files given")
+    binary = [p_.endswith(".blow5") for p_ in paths]
+    if any(b != binary[0] for b in binary) or (not binary[0] and not all(p_.endswith(".slow5") for p_ in paths)):
+        raise ValueError("shards must be all .blow5 or all .slow5 (POD5 shards cannot be concatenated: merge them with the pod5 tools)")
+    n = 0
+    if not binary[0]:
+        with open(out, "w") as fo:
+            for i, p_ in enumerate(paths):
+                with open(p_) as fi:
+                    for line in fi:
+                        if line.startswith(("#", "@")):
+                            if i == 0:
+                                fo.write(line)
+                            continue
+                        fo.write(line)
+                        n += 1
+        return n
+
+    def layout(f):
+        head = f.read(68)
+        if head[:6] != b"BLOW5\x01":
+            raise ValueError(f"{f.name}: not a BLOW5 file")
+        hlen = struct.unpack_from("<I", head, 64)[0]
+        return head, hlen
+
+    with open(out, "wb") as fo:
+        first = None
+        for i, p_ in enumerate(paths):
+            size = os.path.getsize(p_)
+            with open(p_, "rb") as fi:
+                head, hlen = layout(fi)
+                text = fi.read(hlen)
+                if i == 0:
+                    first = (head[:64], [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")])
+                    fo.write(head + text)
+                else:
+                    same = [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]
+                    if head[:64] != first[0] or same != first[1]:
+                        raise ValueError(f"{p_}: header differs from {paths[0]} (another profile, compression or run?)")
+                fi.seek(size - len(BLOW5Writer._EOF))
+                if fi.read() != BLOW5Writer._EOF:
+                    raise ValueError(f"{p_}: no end-of-file marker (truncated shard?)")
+                # count the records while copying them: [u64 size][body] ...
+                pos, end = 68 + hlen, size - len(BLOW5Writer._EOF)
+                fi.seek(pos)
+                while pos < end:
+                    (rec,) = struct.unpack("<Q", fi.read(8))
+                    fo.write(struct.pack("<Q", rec))
+                    left = rec
+                    while left:
+                        blk = fi.read(min(left, 1 << 24))
+                        if not blk:
+                            raise ValueError(f"{p_}: truncated record")
+                        fo.write(blk)
+                        left -= len(blk)
+                    pos += 8 + rec
+                    n += 1
+        fo.write(BLOW5Writer._EOF)
+    return n
+
+
 def read_slow5(path):
     """Minimal SLOW5 ASCII reader (tests only)."""
     header, recs = [], []

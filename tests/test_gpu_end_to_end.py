@@ -273,6 +273,21 @@ def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
         assert a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
         assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
     assert len({r["read_id"] for r in parts}) == 30
+    # the same job as ONE command: `predict --gpus 3` starts its three ranks itself (children under torch.distributed.run; here
+    # all on this box's one GPU), `merge-shards` joins their files
+    for rank in range(3):
+        os.remove(tmp_path / f"out.rank{rank}.blow5")
+    r = subprocess.run(base + ["-o", str(tmp_path / "out.blow5"), "--gpus", "3"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=dict(env0, S2S_ONE_GPU="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    shards = [str(tmp_path / f"out.rank{rank}.blow5") for rank in range(3)]
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "merge-shards", *shards, "-o", str(tmp_path / "merged.blow5")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300, env=env0)
+    assert r.returncode == 0 and "30 records" in r.stdout, r.stdout + r.stderr
+    _, merged = signal_io.read_blow5(str(tmp_path / "merged.blow5"))
+    for a, b in zip(merged, one):
+        assert np.array_equal(a["signal"], b["signal"]) and a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
+        assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
 
 
 def test_rank_shards_in_read_mode_skip_dropped_reads(tmp_path):

@@ -444,6 +444,69 @@ def test_shard_writers_continue_the_single_process_run(tmp_path):
         assert len({str(r["read_id"]) for r in parts}) == 7
 
 
+def test_merge_shards_equals_the_single_process_file(tmp_path):
+    """`seq2squiggle_amd merge-shards`: the out.rankN files of a sharded run concatenate into the file one process writes
+    (same records, ids and read numbers in order; one header, one end-of-file marker); bad inputs are refused."""
+    prof = U.get_profile("dna-r10-prom")
+    rng = np.random.default_rng(5)
+    lens = rng.integers(3, 4000, 11)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    flat = rng.normal(600, 60, offs[-1]).astype(np.int16)
+    ids = [f"read{i}" for i in range(11)]
+    for ext, rd in (("blow5", signal_io.read_blow5), ("slow5", signal_io.read_slow5)):
+        np.random.seed(4)
+        w = signal_io.BLOW5Writer(str(tmp_path / f"one.{ext}"), prof, False, "dna-r10-prom", False)
+        w.save_dac(ids, flat, offs)
+        shards = []
+        for r, (lo, hi) in enumerate(((0, 4), (4, 4), (4, 11))):              # the middle rank has no reads
+            np.random.seed(4)
+            path = parallel.rank_output_path(str(tmp_path / f"out.{ext}"), r, 3)
+            w = signal_io.BLOW5Writer(path, prof, False, "dna-r10-prom", False)
+            if lo:
+                w.start_at(lo)
+            w.save_dac(ids[lo:hi], flat[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo])
+            shards.append(path)
+        merged = str(tmp_path / f"merged.{ext}")
+        r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "merge-shards", *shards, "-o", merged], cwd=ROOT,
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "11 records" in r.stdout, r.stdout + r.stderr
+        h1, one = rd(str(tmp_path / f"one.{ext}"))
+        h2, got = rd(merged)
+        assert len(got) == 11
+        for a, b in zip(got, one):
+            assert a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"] and a["offset"] == b["offset"]
+            assert a["median_before"] == b["median_before"] and np.array_equal(a["signal"], b["signal"])
+            assert all(a[k] == b[k] for k in a if k not in ("signal", "start_time"))   # start_time counts per shard file (start_at)
+        if ext == "blow5":                                                    # one header, one end-of-file marker, nothing else added
+            a, b = open(merged, "rb").read(), open(tmp_path / "one.blow5", "rb").read()
+            assert len(a) == len(b) and a[-5:] == b[-5:] and a[:64] == b[:64]
+    # refusals: mixed containers, a truncated shard, a shard of another profile
+    with pytest.raises(ValueError, match="all .blow5 or all .slow5"):
+        signal_io.merge_shards([str(tmp_path / "one.blow5"), str(tmp_path / "one.slow5")], str(tmp_path / "x.blow5"))
+    cut = tmp_path / "cut.blow5"
+    cut.write_bytes(open(tmp_path / "one.blow5", "rb").read()[:-9])
+    with pytest.raises(ValueError, match="end-of-file"):
+        signal_io.merge_shards([str(tmp_path / "one.blow5"), str(cut)], str(tmp_path / "x.blow5"))
+    other = signal_io.BLOW5Writer(str(tmp_path / "rna.blow5"), U.get_profile("rna-004-prom"), False, "rna-004-prom", False)
+    other.save_dac(ids[:1], flat[:offs[1]], offs[:2])
+    with pytest.raises(ValueError, match="header differs"):
+        signal_io.merge_shards([str(tmp_path / "one.blow5"), str(tmp_path / "rna.blow5")], str(tmp_path / "x.blow5"))
+
+
+def test_predict_gpus_option_starts_one_rank_per_gpu():
+    """`predict --gpus N` outside torchrun re-launches the same command line under torch.distributed.run (children, never exec);
+    inside a rank (WORLD_SIZE set) the option is inert."""
+    import json
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict", "g.fa", "--gpus", "8", "-o", "o.pod5", "-c", "30",
+                        "--gpus=8", "--seed", "7"], cwd=ROOT, capture_output=True, text=True,
+                       env={k: v for k, v in dict(os.environ, S2S_DRY_LAUNCH="1").items() if k != "WORLD_SIZE"})
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["dry_launch"]
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("seq2squiggle_amd") + 1:] == ["predict", "g.fa", "-o", "o.pod5", "-c", "30", "--seed", "7"]
+
+
 _SEED_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
