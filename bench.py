@@ -268,48 +268,73 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
     configs[2] scaled to the rank count (lambda genome -n 12500 x world -r 5000: inference_run shards the read set by RANK /
     WORLD_SIZE exactly as `torchrun ... seq2squiggle_amd predict` does -- shared seed, native sampler skip-ahead, per-rank
     out.rankN.blow5 on /dev/shm), all ranks at once: host threads are cpu_share() = quota / LOCAL_WORLD_SIZE per rank, the
-    FASTA is parsed and the sampler replayed by every rank.  Wall = max over ranks between two barriers."""
+    FASTA is parsed and the sampler replayed by every rank.  Wall = max over ranks between two barriers.
+
+    The leg must never cost the headline line: its barriers and its gather run on a gloo group of their own with a short timeout
+    (a rank that died would otherwise hold the others in an RCCL barrier for ten minutes), a rank whose run raises still reaches
+    both barriers and reports the error, and the output directory is chosen by free space (1.3 GB per rank and pass)."""
+    import shutil
     import tempfile
+    from datetime import timedelta
     from seq2squiggle_amd.cli import set_config
     from seq2squiggle_amd.inference import inference_run
     from seq2squiggle_amd.signal_io import cpu_share
     from seq2squiggle_amd.utils import set_seeds
     fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
-    out_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    grp = dist.new_group(backend="gloo", timeout=timedelta(seconds=300))
     n_total = 12500 * world
+    need = 1.6e9 * int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    choice = [None]
+    if rank == 0:
+        for d in ("/dev/shm", tempfile.gettempdir()):
+            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need:
+                choice[0] = d
+                break
+    dist.broadcast_object_list(choice, src=0, group=grp)
+    out_dir = choice[0]
+    if out_dir is None:
+        return {"skipped": f"no directory with {need / 1e9:.0f} GB free for the rank shard files"} if rank == 0 else None
 
     def run():
-        with tempfile.TemporaryDirectory(dir=out_dir) as td:
+        td = tempfile.mkdtemp(dir=out_dir)
+        err, own, chunks, size = None, 0.0, 0, 0
+        try:
             set_seeds(42)
-            dist.barrier()
+            dist.barrier(group=grp)
             t0 = time.perf_counter()
-            m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
-                              fasta=fasta, read_input=False, n=n_total, r=5000, c=-1, out=os.path.join(td, "o.blow5"),
-                              profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True,
-                              duration_sampling=True, distr="expon", predict_batch_size=1024, export_every_n_samples=1000000,
-                              sample_rate=None, bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
-                              median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
-                              preserve_read_ids=False, seed=42, mode=mode)
-            own = time.perf_counter() - t0
-            dist.barrier()
+            try:
+                m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
+                                  fasta=fasta, read_input=False, n=n_total, r=5000, c=-1, out=os.path.join(td, "o.blow5"),
+                                  profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True,
+                                  duration_sampling=True, distr="expon", predict_batch_size=1024, export_every_n_samples=1000000,
+                                  sample_rate=None, bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
+                                  median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
+                                  preserve_read_ids=False, seed=42, mode=mode)
+                own = time.perf_counter() - t0
+                first = m.first_global_chunk if hasattr(m, "first_global_chunk") else 0
+                chunks = m.chunks_done - first
+                size = sum(os.path.getsize(os.path.join(td, f)) for f in os.listdir(td))
+                m.engine.close()
+            except Exception as e:                      # this rank still meets the others at the barrier below
+                err = f"rank {rank}: {type(e).__name__}: {e}"
+            dist.barrier(group=grp)
             wall = time.perf_counter() - t0
-            first = m.first_global_chunk if hasattr(m, "first_global_chunk") else 0
-            chunks = m.chunks_done - first
-            size = sum(os.path.getsize(os.path.join(td, f)) for f in os.listdir(td))
-            m.engine.close()
-        return own, wall, chunks, size
-    run()                                  # the first call pays the process's one-time costs (pinned buffers, thread pools)
-    own, wall, chunks, size = run()
-    vals = torch.tensor([own, wall, float(chunks), float(size), float(cpu_share())], dtype=torch.float64,
-                        device=dev if dist.get_backend() == "nccl" else "cpu")
-    allv = [torch.zeros_like(vals) for _ in range(world)]
-    dist.all_gather(allv, vals)
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+        return own, wall, chunks, size, err
+    first_pass = run()                     # the first call pays the process's one-time costs (pinned buffers, thread pools)
+    own, wall, chunks, size, err = run() if first_pass[4] is None else first_pass
+    rows = [None] * world
+    dist.all_gather_object(rows, (own, wall, float(chunks), float(size), float(cpu_share()), err), group=grp)
+    dist.destroy_process_group(grp)
     if rank != 0:
         return None
-    rows = [[float(x) for x in v.cpu()] for v in allv]
+    errs = [r[5] for r in rows if r[5]]
+    if errs:
+        return {"error": errs}
     wall = max(r[1] for r in rows)
     total = sum(r[2] for r in rows)
-    return {"workload": f"example lambda genome -n {n_total} -r 5000 -> out.rankN.blow5 on {out_dir or tempfile.gettempdir()}: "
+    return {"workload": f"example lambda genome -n {n_total} -r 5000 -> out.rankN.blow5 on {out_dir}: "
                         f"BASELINE configs[2]'s per-GPU share on each of {world} ranks, sharded by inference_run",
             "seconds": wall, "chunks": total, "chunks_per_sec": total / wall, "reads_per_sec": n_total / wall,
             "per_rank_seconds": [r[0] for r in rows], "per_rank_chunks": [r[2] for r in rows],
@@ -454,9 +479,13 @@ def main():
         torch.cuda.synchronize()
         small_rate = reps * small / (time.perf_counter() - t1)
 
-    sharded = None
+    sharded, sharded_failed = None, False
     if dist and (world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST")) and not a.no_cpu_baseline:      # (the env var: the leg's RCCL calls on one GPU)
-        sharded = end_to_end_sharded(a.mode, dist, rank, world, dev)
+        try:
+            sharded = end_to_end_sharded(a.mode, dist, rank, world, dev)
+        except Exception as e:                                 # (a lost rank, a gloo timeout): the headline line still goes out
+            sharded = {"error": [f"rank {rank}: {type(e).__name__}: {e}"]}
+            sharded_failed = True
     if rank == 0:
         chunks_total = B * a.steps * world
         chunks_s = chunks_total / el
@@ -504,7 +533,8 @@ def main():
         }
         if sharded:
             out["end_to_end_sharded"] = sharded
-            out["end_to_end_sharded"]["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
+            if "chunks_per_sec" in sharded:
+                out["end_to_end_sharded"]["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
         if one_gpu:
             out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 (gloo barrier) -- NOT a scaling measurement"
         if world == 1 and not a.no_cpu_baseline:
@@ -515,6 +545,8 @@ def main():
                 out["reduced_precision"] = reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if sharded_failed:
+        os._exit(0)                                            # the groups are in an unknown state: no collective shutdown
     eng.close()
     if dist:
         dist.destroy_process_group()

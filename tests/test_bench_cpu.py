@@ -48,3 +48,41 @@ def test_child_failure_propagates():
 def test_mismatched_world_size_is_refused():
     p = _run("--gpus", "4", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+_SHARDED_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import bench
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+out = bench.end_to_end_sharded("f16x3", dist, rank, world, "cpu")
+if rank == 0:
+    print("SHARDED " + json.dumps(out))
+else:
+    assert out is None
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_leg_reports_a_failing_rank_instead_of_hanging(tmp_path):
+    """The N > 1 end-to-end leg must never cost the headline line: here (no GPU) every rank's inference_run raises; both ranks
+    still meet at the leg's barriers, rank 0 gets the errors of all ranks, nothing hangs and nothing is left on disk."""
+    if os.path.exists("/dev/kfd"):
+        import pytest
+        pytest.skip("a GPU box would run the leg for real (tests/test_gpu_end_to_end.py does)")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "w.py"
+    script.write_text(_SHARDED_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["TMPDIR"] = str(tmp_path)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
+    line = [l for l in p.stdout.splitlines() if l.startswith("SHARDED ")]
+    assert p.returncode == 0 and len(line) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    out = json.loads(line[0][8:])
+    assert sorted(e.split(":")[0] for e in out["error"]) == ["rank 0", "rank 1"]
