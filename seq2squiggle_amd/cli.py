@@ -155,9 +155,9 @@ def _launch_ranks(gpus: int) -> int:
 
 @main.command("merge-shards")
 @click.argument("shards", nargs=-1, required=True, type=click.Path(exists=True, dir_okay=False))
-@click.option("-o", "--out", required=True, type=click.Path(dir_okay=False), help="Merged .blow5 / .slow5 file.")
+@click.option("-o", "--out", required=True, type=click.Path(dir_okay=False), help="Merged .blow5 / .slow5 / .pod5 file.")
 def merge_shards(shards, out):
-    """Concatenate the OUT.rankN.blow5 (or .slow5) shard files of a multi-GPU run, in the order given, into one file.
+    """Concatenate the OUT.rankN.blow5 (or .slow5 / .pod5) shard files of a multi-GPU run, in the order given, into one file.
     (Read ids and read numbers already continue across the shards of one run.)"""
     from .signal_io import merge_shards as _merge
     n = _merge(list(shards), out)

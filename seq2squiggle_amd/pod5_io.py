@@ -398,10 +398,12 @@ def read_pod5(path: str) -> dict:
             "run_info": run_t.to_pylist(), "reads": reads, "signal_rows": sig.num_rows}
 
 
-def iter_pod5(path: str):
+def iter_pod5(path: str, decode: bool = True):
     """read_pod5() for files that do not fit in memory: the file is memory-mapped, the reads table (about 100 B per read) is read
     whole, and the signal table is walked one record batch (SIGNAL_BATCH_ROWS rows) at a time -- yields (row dict without
-    `signal`, int16 samples) per read in file order; same container checks as read_pod5."""
+    `signal`, int16 samples) per read in file order; same container checks as read_pod5.  decode=False (VBZ files only) yields
+    the read's signal-table rows as they are stored instead of its samples: [(VBZ blob, sample count), ...]; the row dict then
+    carries the run-info record of the read as `run_info_record`."""
     pa = _pa()
     src = pa.memory_map(path, "r")
     buf = src.read_buffer()
@@ -437,12 +439,45 @@ def iter_pod5(path: str):
                 col = col.storage
             cache.update(i=b, col=col, counts=rb.column(rb.schema.get_field_index("samples")).to_numpy())
         col, n = cache["col"], int(cache["counts"][j])
+        if not decode:
+            return (col[j].as_buffer().to_pybytes(), n)
         if vbz:
             from .codecs import vbz_decompress
             return vbz_decompress(col[j].as_buffer(), n)
         return np.asarray(col[j].values.to_numpy(zero_copy_only=False), dtype=np.int16)
     reads_t = files[CT_READS]
+    if not decode:
+        if not vbz:
+            raise ValueError(f"{path}: decode=False needs a VBZ-compressed signal table")
+        runs = {ri["acquisition_id"]: ri for ri in files[CT_RUN_INFO].read_all().to_pylist()}
     for b in range(reads_t.num_record_batches):
         for r in reads_t.get_batch(b).to_pylist():
+            if not decode:
+                yield dict(r, read_id=uuid.UUID(bytes=r["read_id"]), run_info_record=runs[r["run_info"]]), [row(i) for i in r["signal"]]
+                continue
             raw = np.concatenate([row(i) for i in r["signal"]]) if r["signal"] else np.zeros(0, np.int16)
             yield dict(r, read_id=uuid.UUID(bytes=r["read_id"])), raw
+
+
+def merge_pod5(paths: Sequence[str], out: str) -> int:
+    """Concatenate POD5 files written by this package (the out.rankN.pod5 shards of a multi-process run) into one file: reads in
+    the order given, their VBZ signal rows copied as stored (nothing is decoded), run-info records united by acquisition id, one
+    reads table.  Streams shard by shard; memory = one signal batch + 100 B per read.  -> number of reads."""
+    n = 0
+    with Pod5FileWriter(out, signal_compression="vbz") as w:
+        for p_ in paths:
+            batch = []
+            for r, rows in iter_pod5(p_, decode=False):
+                ri = dict(r["run_info_record"])
+                ri["context_tags"], ri["tracking_id"] = dict(ri["context_tags"]), dict(ri["tracking_id"])
+                batch.append(dict(read_id=r["read_id"], vbz_rows=rows, num_samples=r["num_samples"], read_number=r["read_number"],
+                                  start_sample=r["start"], median_before=r["median_before"], channel=r["channel"], well=r["well"],
+                                  pore_type=r["pore_type"], calibration_offset=r["calibration_offset"],
+                                  calibration_scale=r["calibration_scale"], end_reason=r["end_reason"],
+                                  end_reason_forced=r["end_reason_forced"], run_info=ri))
+                n += 1
+                if len(batch) >= 256:
+                    w.add_reads(batch)
+                    batch = []
+            w.add_reads(batch)
+    return n

@@ -419,16 +419,21 @@ def iter_blow5(path):
 
 
 def merge_shards(paths, out: str) -> int:
-    """Concatenate BLOW5 (or SLOW5 ASCII) shard files with identical headers -- the out.rankN files of a sharded run
+    """Concatenate BLOW5 (or SLOW5 ASCII) shard files with identical headers (POD5 shards: pod5_io.merge_pod5) -- the out.rankN files of a sharded run
     (parallel.rank_output_path) -- into `out`: header of the first shard, every shard's records in order, one end-of-file marker.
     Streams; nothing is decompressed.  -> number of records.  Header attributes that differ between shards (only the wall-clock
     exp_start_time may) are taken from the first."""
     import shutil
     if not paths:
         raise ValueError("no shard files given")
+    if all(p_.endswith(".pod5") for p_ in paths):
+        if not out.endswith(".pod5"):
+            raise ValueError("POD5 shards merge into a .pod5 file")
+        from .pod5_io import merge_pod5
+        return merge_pod5(paths, out)
     binary = [p_.endswith(".blow5") for p_ in paths]
     if any(b != binary[0] for b in binary) or (not binary[0] and not all(p_.endswith(".slow5") for p_ in paths)):
-        raise ValueError("shards must be all .blow5 or all .slow5 (POD5 shards cannot be concatenated: merge them with the pod5 tools)")
+        raise ValueError("shards must be all .blow5, all .slow5 or all .pod5")
     n = 0
     if not binary[0]:
         with open(out, "w") as fo:

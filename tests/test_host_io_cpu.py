@@ -481,7 +481,7 @@ def test_merge_shards_equals_the_single_process_file(tmp_path):
             a, b = open(merged, "rb").read(), open(tmp_path / "one.blow5", "rb").read()
             assert len(a) == len(b) and a[-5:] == b[-5:] and a[:64] == b[:64]
     # refusals: mixed containers, a truncated shard, a shard of another profile
-    with pytest.raises(ValueError, match="all .blow5 or all .slow5"):
+    with pytest.raises(ValueError, match="all .blow5, all .slow5 or all .pod5"):
         signal_io.merge_shards([str(tmp_path / "one.blow5"), str(tmp_path / "one.slow5")], str(tmp_path / "x.blow5"))
     cut = tmp_path / "cut.blow5"
     cut.write_bytes(open(tmp_path / "one.blow5", "rb").read()[:-9])
@@ -491,6 +491,45 @@ def test_merge_shards_equals_the_single_process_file(tmp_path):
     other.save_dac(ids[:1], flat[:offs[1]], offs[:2])
     with pytest.raises(ValueError, match="header differs"):
         signal_io.merge_shards([str(tmp_path / "one.blow5"), str(tmp_path / "rna.blow5")], str(tmp_path / "x.blow5"))
+
+
+def test_merge_pod5_shards_equals_the_single_process_file(tmp_path):
+    """POD5 rank shards merge into one container with the single-process run's reads: ids, numbers, calibration, samples; the VBZ
+    rows are copied as stored (also reads longer than one signal row, and a shard without reads)."""
+    from seq2squiggle_amd import pod5_io
+    prof = U.get_profile("dna-r10-prom")
+    rng = np.random.default_rng(6)
+    lens = np.array([5, 300, 102400, 102401, 250000, 17, 4000, 1, 64000])
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    flat = (600 + 40 * rng.standard_normal(offs[-1])).astype(np.int16)
+    ids = [f"read{i}" for i in range(len(lens))]
+    np.random.seed(8)
+    w = signal_io.POD5Writer(str(tmp_path / "one.pod5"), prof, False, "dna-r10-prom", False)
+    w.write_records(w.dac_records(ids, flat, offs))
+    w.close()
+    shards = []
+    for r, (lo, hi) in enumerate(((0, 3), (3, 3), (3, 9))):
+        np.random.seed(8)
+        path = parallel.rank_output_path(str(tmp_path / "out.pod5"), r, 3)
+        w = signal_io.POD5Writer(path, prof, False, "dna-r10-prom", False)
+        if lo:
+            w.start_at(lo)
+        w.write_records(w.dac_records(ids[lo:hi], flat[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo]))
+        w.close()
+        shards.append(path)
+    merged = str(tmp_path / "merged.pod5")
+    r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "merge-shards", *shards, "-o", merged], cwd=ROOT,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "9 records" in r.stdout, r.stdout + r.stderr
+    one, got = pod5_io.read_pod5(str(tmp_path / "one.pod5")), pod5_io.read_pod5(merged)
+    assert len(got["reads"]) == 9 and len(got["run_info"]) == 1 and got["signal_rows"] == one["signal_rows"]
+    for a, b in zip(got["reads"], one["reads"]):
+        assert a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"] and a["num_samples"] == b["num_samples"]
+        assert a["calibration_offset"] == b["calibration_offset"] and a["median_before"] == b["median_before"]
+        assert a["pore_type"] == b["pore_type"] and a["end_reason"] == b["end_reason"] and np.array_equal(a["signal"], b["signal"])
+    assert [len(r["signal"]) for r in got["reads"]] == list(lens)
+    with pytest.raises(ValueError, match=".pod5 file"):
+        signal_io.merge_shards(shards, str(tmp_path / "x.blow5"))
 
 
 def test_predict_gpus_option_starts_one_rank_per_gpu():
