@@ -146,10 +146,14 @@ def _copy_streams(dev):
 def super_batches(reads: Iterable[Tuple[str, str]], k: int, max_chunks: int):
     """Whole reads grouped into super-batches of about max_chunks chunks (reads too short for one chunk are dropped).  The first
     groups are short (1/8, 1/4, 1/2 of max_chunks): the GPU starts as soon as a few reads exist, and the host, which prepares a
-    chunk faster than the GPU predicts one, is ahead from then on.  The last ones shrink again when the iterable says how many
-    reads are left (operator.length_hint: lists, utils.CountedReads): what remains after the GPU's last kernel is then the
-    D2H + compression + write of a small super-batch only."""
+    chunk faster than the GPU predicts one, is ahead from then on.  When the iterable says how many reads are left
+    (operator.length_hint: lists, utils.CountedReads) the groups of a LONG job go on doubling, up to GROW x max_chunks while at
+    least four groups of that size remain -- the export and codec kernels between two predict launches cost the same 0.1-0.3 ms
+    whatever the size (they do not fill the GPU), and a predict launch has its own ramp and tail: 131,072 instead of 32,768 chunks
+    per group is + 3.5 % end to end into .pod5 on one GPU's share of BASELINE configs[4] -- and the last ones shrink again: what
+    remains after the GPU's last kernel is then the D2H + compression + write of a small super-batch only."""
     import operator
+    GROW = 4
     floor = max(max_chunks // 8, 1)
     ramp = want = floor
     seen_reads = seen_chunks = 0
@@ -167,8 +171,10 @@ def super_batches(reads: Iterable[Tuple[str, str]], k: int, max_chunks: int):
         if n >= want:
             yield group
             group, n = [], 0
-            ramp = want = min(2 * ramp, max_chunks)
             left = operator.length_hint(reads, 0) * seen_chunks // seen_reads      # chunks still to come; 0: not known
+            ramp = want = min(2 * ramp, GROW * max_chunks)
+            while want > max_chunks and left < 4 * want:
+                want //= 2
             if 0 < left < 2 * want:
                 want = max(left // 2, floor)
     if group:
@@ -199,7 +205,7 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
     import collections
     pending = collections.deque()   # writer jobs in flight on the (single) writer thread, oldest first: at most MAX_PENDING super-batches
     MAX_PENDING = 3                 # of records wait there (~17 MB each), so a slow batch on the writer does not stall the next launch
-    inflight = None           # (ids, pinned offsets, pinned samples, copy-done event) of the super-batch on the GPU
+    inflight = None           # (ids, device buffer, layout, kernels-done event) of the super-batch on the GPU
     # copy_stream: D2H of finished super-batches; up_stream: H2D of the next one (its own stream: never queued behind a D2H that
     # waits for kernels)
     copy_stream, up_stream = _copy_streams(dev)
@@ -267,18 +273,26 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             mark("export queued")
         ready = torch.cuda.Event()
         ready.record(main)
-        with torch.cuda.stream(copy_stream):      # its own stream: beside the next super-batch's kernels, not queued behind them
-            copy_stream.wait_event(ready)
+        mark("launched")
+        return names, buf, (R, head, row_read if gpu_rows else None), ready
+
+    def collect(job):
+        ids, buf, (R, head, row_read), ready = job
+        # The D2H is issued only once the super-batch's kernels have FINISHED (the calling thread has nothing else to do at this
+        # point: the next super-batch is already queued behind them).  Queued earlier, behind a stream-side wait for `ready`, the
+        # runtime carries the copy out as a 256-workgroup shader copy, and no wave of it fits on a CU while the next predict kernel
+        # holds the register files: it ended with THAT kernel, one super-batch late, and every second launch then waited 1.5-2.5 ms
+        # for this thread (rocprofv3 --kernel-trace: 9 % of the GPU's time on one GPU's share of configs[4]).  A copy with nothing
+        # pending in front of it goes through the DMA engines, beside the running kernel (tools/d2h_probe.py: 9 MB in 0.23 ms).
+        mark("wait gpu")
+        ready.synchronize()
+        mark("d2h")
+        with torch.cuda.stream(copy_stream):
             buf_h = torch.empty(buf.shape, dtype=torch.uint8, pin_memory=True)
             buf_h.copy_(buf, non_blocking=True)
             buf.record_stream(copy_stream)
             done = torch.cuda.Event()
             done.record(copy_stream)
-        mark("launched")
-        return names, buf_h, (R, head, row_read if gpu_rows else None), done
-
-    def collect(job):
-        ids, buf_h, (R, head, row_read), done = job
         mark("wait d2h")
         done.synchronize()
         mark("records")

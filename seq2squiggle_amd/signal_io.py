@@ -512,7 +512,8 @@ def read_slow5(path):
 class POD5Writer:
     """The reference's POD5Writer (signal_io.py:175-287) on the native container writer of pod5_io.py.  The records
     (ids, calibration, int16 samples, run info) are pinned against the reference; the container is UNVALIDATED against
-    libpod5 (see pod5_io.py) and stores uncompressed samples."""
+    libpod5 (see pod5_io.py; tools/validate_containers.py checks it where the pod5 package exists); signal rows are VBZ-compressed
+    like libpod5's (S2S_POD5_SIGNAL=none stores them uncompressed)."""
 
     def __init__(self, filename, profile, ideal_mode, profile_name, preserve_read_ids):
         self.filename = str(filename)

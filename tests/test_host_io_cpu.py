@@ -612,6 +612,17 @@ def test_super_batches_ramp_and_taper():
             assert sizes[-1] < 8192 and sizes[-2] <= 16384 + 600           # the tail shrinks
         else:
             assert all(sz >= 32768 for sz in sizes[3:-1])
+    # a long job whose length is known: the groups go on doubling to 4 x max_chunks while four of that size remain, step down again
+    # (never below max_chunks before the tail) and end small; an unknown length never exceeds max_chunks
+    long_reads = [("A" * 10008, f"r{i}") for i in range(6000)]                      # 625 chunks each, 3.75 M chunks
+    groups = list(super_batches(CountedReads(iter(long_reads), len(long_reads)), 9, 32768))
+    assert [r for g in groups for r in g] == long_reads
+    sizes = [625 * len(g) for g in groups]
+    assert sizes[:4] == [4375, 8750, 16875, 33125] and sizes[4] >= 65536 and max(sizes) >= 131072 and max(sizes) < 131072 + 625
+    peak = sizes.index(max(sizes))
+    assert all(a >= b - 625 for a, b in zip(sizes[peak:], sizes[peak + 1:]))         # non-increasing from the peak on
+    assert sizes[-1] < 8192 and len(sizes) < 45 and sum(sz > 131000 for sz in sizes) >= 22
+    assert max(625 * len(g) for g in super_batches((r for r in long_reads), 9, 32768)) < 32768 + 625
     assert list(super_batches([], 9, 1024)) == [] and list(super_batches([("AC", "x")], 9, 1024)) == []
 
 
