@@ -3,6 +3,7 @@
 #   gpurun_out/<tag>/stats_{f16x3,f32}: rocprofv3 --kernel-trace --stats of bench.py --steps 3 (+ the bench line it printed)
 #   gpurun_out/<tag>/pmc_{f16x3,f32}:   the PMC passes of tools/pmc_run.sh
 #   gpurun_out/<tag>/bench_f16x3.json:  the plain default bench line (CPU baseline + end-to-end included)
+#   gpurun_out/<tag>/power_<mode>.txt:   rocm-smi power / clock samples under the kernel (tools/power_probe.sh)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$1
 mkdir -p $R/gpurun_out/$T
@@ -27,4 +28,6 @@ for f in ("diag_phases.txt", "diag_phases_f32.txt"):
 json.dump(d, open(sys.argv[1] + "/diag_clock.json", "w"))
 PY
 timeout -k 10 120 tools/probes/pass_probe > gpurun_out/$T/pass_probe.txt 2>&1
+# socket power + shader clock under the kernel (rocm-smi), per mode
+for m in f16x3 f32 f16; do timeout -k 10 120 bash tools/power_probe.sh $m > /dev/null 2>&1; cp gpurun_out/power_$m.txt gpurun_out/$T/; done
 ls gpurun_out/$T gpurun_out/$T/stats_f16x3
