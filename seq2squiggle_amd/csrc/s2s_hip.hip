@@ -592,23 +592,40 @@ __global__ __launch_bounds__(256) void s2s_count_kernel(const float* __restrict_
     if (lane == 0) counts[b] = n;
 }
 
-// exclusive scan of counts[B] -> offs[B+1] (int64), one workgroup walking the array
+// exclusive scan of counts[B] -> offs[B+1] (int64), one workgroup walking the array, 8 consecutive elements per thread and step
+// (131,072 chunk counts = 16 steps)
 __global__ __launch_bounds__(1024) void s2s_scan_kernel(const int* __restrict__ counts, int B, long long* __restrict__ offs) {
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < B; base += 1024) {
-        const int i = base + tid;
-        long long v = (i < B) ? counts[i] : 0, x = v;
+    for (int base = 0; base < B; base += 8192) {
+        const int i0 = base + 8 * tid;
+        int c[8];
+        if (i0 + 8 <= B) {                                     // (the workspace is 16-byte aligned, i0 a multiple of 8)
+            const int4 a = *reinterpret_cast<const int4*>(counts + i0), b = *reinterpret_cast<const int4*>(counts + i0 + 4);
+            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = (i0 + k < B) ? counts[i0 + k] : 0;
+        }
+        long long v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += c[k];
+        long long x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
         if (lane == 63) wsum[w] = x;
         __syncthreads();
         long long pre = carry_s;
         for (int j = 0; j < w; ++j) pre += wsum[j];
-        if (i < B) offs[i] = pre + x - v;
+        long long run = pre + x - v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < B) offs[i0 + k] = run;
+            run += c[k];
+        }
         __syncthreads();
         if (tid == 1023) carry_s = pre + x;
         __syncthreads();
@@ -690,17 +707,33 @@ __global__ __launch_bounds__(256) void s2s_svb_kernel(const short* __restrict__ 
     }
     if (tid == 0) carry_s = 0;
     __syncthreads();
+    // a thread's nine samples of a step (its eight + the one before them) are loaded one step ahead: the steps of a row are a
+    // serial chain (the carry), and without the prefetch each one began with a full memory round trip
+    short raw[9];
+    auto fetch = [&](long long t0) {
+        const long long j0 = t0 + 8 * (long long)tid;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const long long j = j0 + i - 1;
+            raw[i] = (j >= 0 && j < n) ? x[j] : (short)0;     // (the delta of a row's first value is against 0)
+        }
+    };
+    fetch(0);
     for (long long t0 = 0; t0 < n; t0 += 2048) {
         const long long j0 = t0 + 8 * (long long)tid;
         unsigned v[8];
         int len[8], tot = 0;
         unsigned key = 0;
-        int prev = (j0 > 0 && j0 <= n) ? x[j0 - 1] : 0;       // (the delta of a row's first value is against 0)
+        int prev = raw[0];
+        short now[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) now[i] = raw[i + 1];
+        if (t0 + 2048 < n) fetch(t0 + 2048);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             len[i] = 0; v[i] = 0;
             if (j0 + i < n) {
-                const int cur = x[j0 + i];
+                const int cur = now[i];
                 if (VARIANT == 32) {
                     const int d = cur - prev;
                     v[i] = ((unsigned)d << 1) ^ (unsigned)(d >> 31);
@@ -1135,7 +1168,7 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     {   // one allocation (each hipMalloc is a driver round trip): weights | hand-off slots | export scratch for the streaming
         // path's usual super-batch, so that its first s2s_export_reads does not have to drain the stream in order to grow it |
         // s2s_svb_encode scratch (rows of a super-batch; POD5: ~6 per 10 kb read)
-        const int cap = 2 * 32768 + 1, rows = 16384;
+        const int cap = 5 * 32768 + 1, rows = 16384;   // run_streaming's largest super-batches (131,072 chunks + one read) fit without a re-allocation
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t o_hand = up(h->arena_floats * sizeof(float));
         const size_t o_counts = o_hand + up((size_t)h->n_wg * S2S_MAX_GROUP * S2S_SLOT_FLOATS * sizeof(float));
