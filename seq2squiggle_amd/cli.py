@@ -84,17 +84,34 @@ def version():
 @click.option("--gpus", default=1, type=int, hidden=True,
               help="Run on this many GPUs of the node: one process per GPU, the read set sharded, one OUT.rankN file per process "
                    "(the same as starting the command under torchrun --nproc-per-node N).")
+@click.option("--keep-shards", is_flag=True, hidden=True,
+              help="With --gpus N: leave the OUT.rankN files as they are instead of merging them into OUT.")
 @click.pass_context
 def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profile, show_advanced_options, noise_sampler,
             duration_sampler, dwell_mean, dwell_std, noise_std, distr, predict_batch_size, export_every_n_samples,
             sample_rate, bps, digitisation, range_val, offset_mean, offset_std, median_before_mean, median_before_std,
-            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode, gpus):
+            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode, gpus, keep_shards):
     """Generate nanopore signals from a reference genome (default) or from reads (--read-input)."""
     import os
     if gpus > 1 and "WORLD_SIZE" not in os.environ:
         # The reference leaves multi-GPU runs to Lightning (devices="auto", DDP: inference.py:430-445); here the command starts its
         # own ranks as CHILD processes -- before anything in this process has touched the GPU -- and returns their exit code.
-        ctx.exit(_launch_ranks(gpus))
+        if fasta is None or out is None:
+            click.echo("FASTA and -o/--out are required")
+            ctx.exit(1)
+        if str(out).endswith(".pod5") and os.path.exists(out) and not keep_shards:
+            raise FileExistsError(f"{out} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
+        rc = _launch_ranks(gpus)
+        if rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
+            # one output file, as the reference writes: the rank files are joined in rank order and removed
+            from .parallel import rank_output_path
+            from .signal_io import merge_shards as _merge
+            shards = [rank_output_path(str(out), r, gpus) for r in range(gpus)]
+            n = _merge(shards, str(out))
+            for p_ in shards:
+                os.remove(p_)
+            click.echo(f"{n} reads from {gpus} ranks -> {out}")
+        ctx.exit(rc)
     from .inference import inference_run
     from .utils import set_seeds, setup_logging
 
@@ -137,7 +154,7 @@ def _launch_ranks(gpus: int) -> int:
         if a == "--gpus":
             skip = True
             continue
-        if a.startswith("--gpus="):
+        if a.startswith("--gpus=") or a == "--keep-shards":
             continue
         argv.append(a)
     with socket.socket() as sk:

@@ -277,14 +277,22 @@ def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
     # all on this box's one GPU), `merge-shards` joins their files
     for rank in range(3):
         os.remove(tmp_path / f"out.rank{rank}.blow5")
-    r = subprocess.run(base + ["-o", str(tmp_path / "out.blow5"), "--gpus", "3"], cwd=ROOT, capture_output=True, text=True,
-                       timeout=900, env=dict(env0, S2S_ONE_GPU="1"))
+    r = subprocess.run(base + ["-o", str(tmp_path / "out.blow5"), "--gpus", "3", "--keep-shards"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=900, env=dict(env0, S2S_ONE_GPU="1"))
     assert r.returncode == 0, r.stderr[-3000:]
     shards = [str(tmp_path / f"out.rank{rank}.blow5") for rank in range(3)]
     r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "merge-shards", *shards, "-o", str(tmp_path / "merged.blow5")],
                        cwd=ROOT, capture_output=True, text=True, timeout=300, env=env0)
     assert r.returncode == 0 and "30 records" in r.stdout, r.stdout + r.stderr
     _, merged = signal_io.read_blow5(str(tmp_path / "merged.blow5"))
+    # without --keep-shards the command itself leaves ONE file, like the reference (here .pod5: re-tabled, VBZ rows copied as stored)
+    r = subprocess.run(base + ["-o", str(tmp_path / "all.pod5"), "--gpus", "2"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=dict(env0, S2S_ONE_GPU="1"))
+    assert r.returncode == 0 and "30 reads from 2 ranks" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("all.")) == ["all.pod5"]
+    from seq2squiggle_amd import pod5_io
+    p5 = pod5_io.read_pod5(str(tmp_path / "all.pod5"))["reads"]
+    assert len(p5) == 30 and all(np.array_equal(a["signal"], b["signal"]) and a["read_number"] == b["read_number"] for a, b in zip(p5, one))
     for a, b in zip(merged, one):
         assert np.array_equal(a["signal"], b["signal"]) and a["read_id"] == b["read_id"] and a["read_number"] == b["read_number"]
         assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
