@@ -429,4 +429,13 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
         load_model.on_predict_epoch_end()
     torch.cuda.synchronize(load_model.device)
     logger.info(f"Predicted {n_chunks} chunks ({n_chunks * 250} padded samples).")
+    shard = rank_output_path(str(out), rank, world)
+    if world > 1 and not os.path.exists(shard) and hasattr(writer, "write_records"):
+        # a rank without reads (more ranks than reads) still leaves its -- empty -- shard, so that the rank files always merge
+
+        def empty():
+            writer.write_records([])
+            if hasattr(writer, "close"):
+                writer.close()
+        _io_executor().submit(empty).result()
     return load_model

@@ -423,12 +423,30 @@ def merge_shards(paths, out: str) -> int:
     (parallel.rank_output_path) -- into `out`: header of the first shard, every shard's records in order, one end-of-file marker.
     Streams; nothing is decompressed.  -> number of records.  Header attributes that differ between shards (only the wall-clock
     exp_start_time may) are taken from the first."""
-    import shutil
     if not paths:
         raise ValueError("no shard files given")
+    missing = [p_ for p_ in paths if not os.path.exists(p_)]
+    if missing:
+        raise FileNotFoundError(f"shard file(s) missing: {', '.join(missing)}")
+    ext = os.path.splitext(out)[1]
+    tmp = out[:len(out) - len(ext)] + ".partial" + ext              # the merged file appears under its name only when it is whole
+    if os.path.exists(tmp):
+        os.remove(tmp)
+    try:
+        n = _merge_shards_into(paths, tmp, out)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return n
+
+
+def _merge_shards_into(paths, out: str, final_name: str) -> int:
     if all(p_.endswith(".pod5") for p_ in paths):
-        if not out.endswith(".pod5"):
+        if not final_name.endswith(".pod5"):
             raise ValueError("POD5 shards merge into a .pod5 file")
+        if os.path.exists(final_name):
+            raise FileExistsError(f"{final_name} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
         from .pod5_io import merge_pod5
         return merge_pod5(paths, out)
     binary = [p_.endswith(".blow5") for p_ in paths]

@@ -298,6 +298,29 @@ def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
         assert a["offset"] == b["offset"] and a["median_before"] == b["median_before"]
 
 
+def test_more_ranks_than_reads(tmp_path):
+    """`--gpus 3` with two reads: the rank without reads leaves an empty shard, the merge takes it, one file with both reads
+    comes out (and equals the single-process file); no partial output appears under the final name when a merge fails."""
+    lam = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+    base = [sys.executable, "-m", "seq2squiggle_amd", "predict", lam, "-n", "2", "-r", "2000", "-m",
+            os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--seed", "9"]
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(base + ["-o", str(tmp_path / "one.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env0)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(base + ["-o", str(tmp_path / "few.blow5"), "--gpus", "3"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=dict(env0, S2S_ONE_GPU="1"))
+    assert r.returncode == 0 and "2 reads from 3 ranks" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("few.")) == ["few.blow5"]
+    _, one = signal_io.read_blow5(str(tmp_path / "one.blow5"))
+    _, few = signal_io.read_blow5(str(tmp_path / "few.blow5"))
+    assert len(few) == len(one) == 2
+    for a, b in zip(few, one):
+        assert a["read_id"] == b["read_id"] and np.array_equal(a["signal"], b["signal"]) and a["offset"] == b["offset"]
+    with pytest.raises(FileNotFoundError):
+        signal_io.merge_shards([str(tmp_path / "one.blow5"), str(tmp_path / "absent.blow5")], str(tmp_path / "m.blow5"))
+    assert not os.path.exists(tmp_path / "m.blow5") and not os.path.exists(tmp_path / "m.partial.blow5")
+
+
 def test_rank_shards_in_read_mode_skip_dropped_reads(tmp_path):
     """--read-input with reads too short for one chunk scattered through the file (they produce no record,
     reference dataloader.py:393-398): the shard writers must count RECORDS, not reads, so that ids, read numbers and
