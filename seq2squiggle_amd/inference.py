@@ -317,6 +317,8 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             mark("writer end")
         pending.append(io.submit(job_))
 
+    t_start = t_log = time.perf_counter()
+    n_reads = 0
     try:
         mark("first read wanted")
         for group in super_batches(reads, k, max_chunks):
@@ -324,6 +326,12 @@ def run_streaming(model, reads: Iterable[Tuple[str, str]], writer, profile_dict:
             if inflight is not None:
                 collect(inflight)
             inflight = job
+            n_reads += len(group)
+            now = time.perf_counter()
+            if now - t_log > 10.0:                 # long jobs: a progress line every ten seconds (the reference shows Lightning's bar)
+                t_log = now
+                logger.info(f"{n_reads} reads, {total} chunks queued after {now - t_start:.0f} s "
+                            f"({total / (now - t_start):.3g} chunks/s)")
         if inflight is not None:
             collect(inflight)
         while pending:

@@ -550,17 +550,12 @@ _SEED_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
 from seq2squiggle_amd import parallel
-s0 = parallel.shared_seed(0)
+s0 = parallel.shared_seed(0)                      # (its own short-lived gloo group: created, used, destroyed inside)
 assert s0 != 0 and parallel.shared_seed(77) == 77
-import torch, torch.distributed as dist
-dist.init_process_group("gloo")
-t = torch.tensor([s0], dtype=torch.int64)
-out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-dist.all_gather(out, t)
-if dist.get_rank() == 0:
-    assert all(int(o) == s0 for o in out), out
-    print("SEED_SHARED", s0)
-dist.destroy_process_group()
+# every rank reports through a file: a second process group in the same processes right after the first one's teardown is a
+# rendezvous race of the TEST's making (it hung one run in eight), not something the product does
+with open(os.path.join(sys.argv[2], "seed.rank%s" % os.environ["RANK"]), "w") as f:
+    f.write(str(s0))
 """
 
 
@@ -568,9 +563,11 @@ def test_seed_zero_is_shared_between_ranks(tmp_path):
     script = tmp_path / "s.py"
     script.write_text(_SEED_WORKER)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT, str(tmp_path)],
                        capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=300)
-    assert "SEED_SHARED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    seeds = [int(open(tmp_path / f"seed.rank{i}").read()) for i in range(2)]
+    assert seeds[0] == seeds[1] != 0
     assert parallel.shared_seed(0) == 0            # single process: left to set_seeds (utils.py:722-741)
 
 
