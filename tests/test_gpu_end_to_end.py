@@ -357,7 +357,7 @@ def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
     the N > 1 code path of the timed loop, the sharded end-to-end leg (each rank: FASTA parse, native sampler skip-ahead,
     its read shard, cpu_share() = quota / LOCAL_WORLD_SIZE threads, its own shard file) and the max-over-ranks timing.
     Checked: one JSON line, both ranks seen, the shards add up to the whole job, and two ranks sharing one GPU move at
-    least 80 % of what one rank moves end to end (a host-side collapse under halved thread counts would show here)."""
+    least 70 % of what one rank moves end to end (a host-side collapse under halved thread counts would show here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["S2S_BENCH_ONE_GPU"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "500"],
@@ -381,4 +381,4 @@ def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
     ratio = e["chunks_per_sec"] / single["chunks_per_sec"]
     print(f"two ranks on one GPU: {e['chunks_per_sec']:.3e} chunks/s end to end ({e['per_rank_cpu_share_threads'][0]} host threads per rank) "
           f"vs one rank {single['chunks_per_sec']:.3e}: x{ratio:.2f}")
-    assert ratio > 0.8, (e, single)
+    assert ratio > 0.7, (e, single)          # measured 0.99-1.04; a host-side collapse under halved thread counts would read <= 0.5
