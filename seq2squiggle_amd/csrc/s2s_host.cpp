@@ -198,6 +198,28 @@ struct BitOut {
         n += bits;
         if (n >= 32) { std::memcpy(p, &acc, 4); p += 4; acc >>= 32; n -= 32; }      // (little-endian host)
     }
+    // Four codes of <= 15 bits each behind < 8 pending bits: one unconditional 8-byte store, the pointer moves by the whole bytes
+    // (the destination has slack behind the stream: see the bound at huff_deflate_piece).
+    inline void put4(uint32_t a, int la, uint32_t b, int lb, uint32_t c, int lc, uint32_t d, int ld) {
+        if (n + la + lb + lc + ld >= 64) {               // four long codes in a row (rare symbols): the 64-bit word would overflow
+            put(a | b << la, la + lb);
+            put(c | d << lc, lc + ld);
+            align_pending();
+            return;
+        }
+        uint64_t v = acc | (uint64_t)a << n;
+        int m = n + la;
+        v |= (uint64_t)b << m; m += lb;
+        v |= (uint64_t)c << m; m += lc;
+        v |= (uint64_t)d << m; m += ld;                  // m < 64
+        std::memcpy(p, &v, 8);
+        p += m >> 3;
+        acc = v >> (m & ~7);
+        n = m & 7;
+    }
+    inline void align_pending() {                        // bring the buffer below 8 pending bits (put4's entry condition)
+        while (n >= 8) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
+    }
     uint8_t* finish() {                                  // pad to a byte boundary
         while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
         n = 0; acc = 0;
@@ -221,18 +243,26 @@ struct Segs {                                            // bytes [lo, hi) of th
 // One piece -> dst (room >= len + len / 128 + 512): [dynamic block | stored blocks when those are smaller][empty stored block,
 // final bit = last].  Returns the bytes written; *adler = Adler-32 of the piece's bytes.
 int64_t huff_deflate_piece(const Segs& in, int64_t lo, int64_t hi, bool last, uint8_t* dst, uint32_t* adler) {
-    uint32_t hist[4][256];
+    uint32_t hist[8][256];                               // eight tables: int16 samples put near-equal bytes two apart
     std::memset(hist, 0, sizeof hist);
     uint32_t ad = 1;
     in.each(lo, hi, [&](const uint8_t* s, int64_t m) {
         ad = (uint32_t)adler32(ad, s, (uInt)m);
         int64_t i = 0;
-        for (; i + 4 <= m; i += 4) { ++hist[0][s[i]]; ++hist[1][s[i + 1]]; ++hist[2][s[i + 2]]; ++hist[3][s[i + 3]]; }
+        for (; i + 8 <= m; i += 8) {
+            uint64_t w;
+            std::memcpy(&w, s + i, 8);
+            ++hist[0][w & 255]; ++hist[1][(w >> 8) & 255]; ++hist[2][(w >> 16) & 255]; ++hist[3][(w >> 24) & 255];
+            ++hist[4][(w >> 32) & 255]; ++hist[5][(w >> 40) & 255]; ++hist[6][(w >> 48) & 255]; ++hist[7][w >> 56];
+        }
         for (; i < m; ++i) ++hist[0][s[i]];
     });
     *adler = ad;
     uint32_t freq[257];
-    for (int i = 0; i < 256; ++i) freq[i] = hist[0][i] + hist[1][i] + hist[2][i] + hist[3][i];
+    for (int i = 0; i < 256; ++i) {
+        freq[i] = 0;
+        for (int k = 0; k < 8; ++k) freq[i] += hist[k][i];
+    }
     freq[256] = 1;                                       // end of block
     uint8_t len[259];
     huff_lengths(freq, 257, 15, len);
@@ -274,10 +304,10 @@ int64_t huff_deflate_piece(const Segs& in, int64_t lo, int64_t hi, bool last, ui
         for (int i = 0; i < 256; ++i) tab[i] = code[i] | (uint32_t)len[i] << 16;
         in.each(lo, hi, [&](const uint8_t* s, int64_t m) {
             int64_t i = 0;
-            for (; i + 2 <= m; i += 2) {                 // two codes (<= 15 bits each) per buffer check
-                const uint32_t t = tab[s[i]], u = tab[s[i + 1]];
-                const int lt = (int)(t >> 16);
-                out.put((t & 0xFFFF) | (u & 0xFFFF) << lt, lt + (int)(u >> 16));
+            out.align_pending();
+            for (; i + 4 <= m; i += 4) {                 // four codes (<= 15 bits each) per store
+                const uint32_t t = tab[s[i]], u = tab[s[i + 1]], v = tab[s[i + 2]], w = tab[s[i + 3]];
+                out.put4(t & 0xFFFF, (int)(t >> 16), u & 0xFFFF, (int)(u >> 16), v & 0xFFFF, (int)(v >> 16), w & 0xFFFF, (int)(w >> 16));
             }
             for (; i < m; ++i) { const uint32_t t = tab[s[i]]; out.put(t & 0xFFFF, (int)(t >> 16)); }
         });

@@ -263,8 +263,14 @@ def test_huffman_only_deflate_streams(tmp_path):
     w = signal_io.BLOW5Writer(str(tmp_path / "h.blow5"), prof, False, "dna-r10-prom", False)
     assert w.deflate == "huffman"
     geo = np.minimum(rng.geometric(0.5, 300000), 40).astype(np.int16)        # p(v) ~ 2^-v: a 40-deep Huffman tree
+    # runs of the rarest byte values (15-bit codes, several in a row at every bit phase: the encoder's four-codes-per-store path
+    # must fall back when they would not fit its 64-bit word) inside a sea of one common value
+    rare = np.zeros(60000, np.int16)
+    for at in range(1000, 59000, 997):
+        k = int(rng.integers(3, 12))
+        rare[at: at + k] = (rng.integers(100, 250, k) | (rng.integers(100, 250, k) << 8)).astype(np.uint16).view(np.int16)
     sigs = [rng.integers(-32768, 32767, 100000).astype(np.int16), np.full(70001, 513, np.int16), geo,
-            np.array([7], np.int16), (600 + rng.normal(0, 30, 500000)).astype(np.int16), np.zeros(2, np.int16)]
+            np.array([7], np.int16), (600 + rng.normal(0, 30, 500000)).astype(np.int16), np.zeros(2, np.int16), rare]
     offs = np.concatenate([[0], np.cumsum([len(x) for x in sigs])])
     np.random.seed(1)
     recs = w.dac_records([f"r{i}" for i in range(len(sigs))], np.concatenate(sigs), offs)
