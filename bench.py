@@ -538,11 +538,18 @@ def main():
         if one_gpu:
             out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 (gloo barrier) -- NOT a scaling measurement"
         if world == 1 and not a.no_cpu_baseline:
-            out["end_to_end"] = end_to_end(a.mode)
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, eng)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            def leg(name, fn, *args):                    # a secondary leg that fails (a full disk, ...) must not cost the line
+                try:
+                    out[name] = fn(*args)
+                except Exception as e:
+                    out[name] = {"error": f"{type(e).__name__}: {e}"}
+                    print(f"bench.py: {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            leg("end_to_end", end_to_end, a.mode)
+            leg("cpu_baseline", cpu_baseline, sd, cfg, eng)
+            if "value" in out["cpu_baseline"]:
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             if a.mode == "f16x3":
-                out["reduced_precision"] = reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
+                leg("reduced_precision", reduced_precision_leg, sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if sharded_failed:
