@@ -291,7 +291,7 @@ __device__ __forceinline__ void mm_unit(f32x4 (&acc)[NQ], const f32x4 (&f)[4], c
 template <int NQ, int NKT, int TV>
 __device__ __forceinline__ void fft_block(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                           float* __restrict__ lds, int qt0, int lane,
-                                          unsigned long long* diag_buf = nullptr) {
+                                          [[maybe_unused]] unsigned long long* diag_buf = nullptr) {
     using G = AttnLds<NKT>;
     DIAG_DECL;
     const int g = lane >> 4, c = lane & 15;

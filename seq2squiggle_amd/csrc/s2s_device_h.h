@@ -515,7 +515,7 @@ __device__ __forceinline__ void load_unit_h(f32x4 (&f)[4], const float* __restri
 template <int NQ, int WAVES, int NKT, int TV, bool LO = true>
 __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const LayerOff L, f32x4 (&X)[NQ][4],
                                             char* __restrict__ lds, int qt0, int wave, int lane, const float one,
-                                            unsigned long long* diag_buf = nullptr, const float* __restrict__ pf_src = nullptr,
+                                            [[maybe_unused]] unsigned long long* diag_buf = nullptr, const float* __restrict__ pf_src = nullptr,
                                             float* __restrict__ pf_dst = nullptr, float* __restrict__ sv_lds = nullptr) {
     using G = AttnLdsH<NQ, WAVES, NKT>;
     // SV: the layer's small vectors (biases, LayerNorm weights: S2S_SV_FLOATS contiguous floats from L.bq_nat, pack_layer) are
@@ -529,7 +529,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
     const int sv_i = wave * 64 + lane;
     f32x4 svv = f32x4{0, 0, 0, 0};
     if (SV && sv_i < S2S_SV_FLOATS / 4) svv = ldg4(W + L.bq_nat + 4 * sv_i);
-    constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH, HB = (HK + 1) / 2;   // 256 keys: 4 passes of 64
+    constexpr int NH = (NKT >= 16) ? 4 : 1, HK = NKT / NH;                       // 256 keys: 4 passes of 64
+    [[maybe_unused]] constexpr int HB = (HK + 1) / 2;
     const int g = lane >> 4, c = lane & 15;
     DIAG_DECL;
     _Float16* __restrict__ Kl = reinterpret_cast<_Float16*>(lds);
@@ -598,7 +599,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
 
-    const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
+    [[maybe_unused]] const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8)
     h8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
@@ -921,7 +922,7 @@ __device__ __forceinline__ void enc_attention_h(const float* __restrict__ W, con
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q][mt] = X[q][mt] + b;
     }
-    const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8): scores in log2 units
+    [[maybe_unused]] const float c1 = 1.4426950408889634f * 0.35355339059327373f;     // log2(e) / sqrt(d_k = 8): scores in log2 units
     const bool low = g < 2;                                           // lane groups of the pair's first head
 #pragma unroll 1
     for (int u = 0; u < 2; ++u) {
