@@ -245,6 +245,17 @@ int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32
                            uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
                            int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i);
 
+/* Plain FASTA text -> cleaned sequences on the host (no GPU): what utils.read_fasta (pysam.FastxFile, utils.py:290-308) and
+ * process_genome (upper-case, non-ACGT -> N: utils.py:594-597) do line by line in the interpreter; every rank of a sharded
+ * run parses the whole reference before its first kernel.  s2s_fasta_count: number of records ('>' first on a line), -2 when
+ * the first non-blank line is no FASTA header (FASTQ, ...).  s2s_fasta_clean: out (>= n bytes) receives the sequences back to
+ * back, line ends removed and lines stripped of blanks; map_acgtn = 1 applies process_genome's mapping; seq_offs [records+1]
+ * delimits them; name_span [2*records]: begin / end of each record's name (first token of its header) inside data.
+ * Returns the number of records, -1 when there are more than max_records. */
+int64_t s2s_fasta_count(const uint8_t* data, int64_t n);
+int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
+                        int64_t* name_span, int64_t max_records);
+
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): per wave of a workgroup (8 rows) 48 per-phase shader-cycle sums
  * since the last call, summed over the workgroups (slots 0-15 decoder phases, 16-18 whole-kernel s_memtime / s_memrealtime /
  * wave count, 32-47 the frontend's own phases; tools/diag_phases.py names them); out384 = [8][48].  S2S_ERR_ARG in a normal build. */

@@ -626,3 +626,77 @@ extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_
     *out_next_read_i = read_i;
     return accepted;
 }
+
+// ---- FASTA text -> cleaned sequences (replaces the line loop of utils.read_fasta + process_genome, reference utils.py:290-308,
+// 594-597, for plain FASTA files): every rank of a sharded run parses the whole reference before its first kernel.
+namespace {
+inline bool fa_blank(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+}  // namespace
+
+// Number of records ('>' in column 0, as pysam / the line loop of utils.read_fasta take it); -2 when the first non-empty line
+// starts with '@' (FASTQ: left to the caller's line loop).
+extern "C" int64_t s2s_fasta_count(const uint8_t* data, int64_t n) {
+    if (!data || n < 0) return S2S_ERR_ARG;
+    int64_t i = 0, recs = 0;
+    bool first = true;
+    while (i < n) {
+        const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(data + i, '\n', (size_t)(n - i)));
+        int64_t end = nl ? nl - data : n;
+        const int64_t next = end + 1;
+        while (end > i && data[end - 1] == '\r') --end;
+        if (end > i) {
+            if (first && data[i] == '@') return -2;
+            first = false;
+            recs += data[i] == '>';
+        }
+        i = next;
+    }
+    return recs;
+}
+
+// out receives the records' sequences back to back: line ends removed, every line stripped of blanks at both ends (as the line
+// loop does), optionally upper-cased with everything but ACGT mapped to N (map_acgtn = 1: process_genome).  seq_offs[r],
+// seq_offs[r+1] delimit record r in out; name_span[2r], name_span[2r+1] delimit its name (the header's first token) in data.
+// Lines before the first header are ignored.  Returns the number of records (<= max_records, else -1).
+extern "C" int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
+                                   int64_t* name_span, int64_t max_records) {
+    if (!data || n < 0 || !out || !seq_offs || !name_span || max_records < 0) return S2S_ERR_ARG;
+    uint8_t tab[256];
+    for (int c = 0; c < 256; ++c) {
+        uint8_t u = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : (uint8_t)c;
+        tab[c] = map_acgtn ? ((u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : (uint8_t)'N') : (uint8_t)c;
+    }
+    int64_t i = 0, recs = 0, o = 0;
+    while (i < n) {
+        const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(data + i, '\n', (size_t)(n - i)));
+        int64_t end = nl ? nl - data : n;
+        const int64_t next = end + 1;
+        while (end > i && data[end - 1] == '\r') --end;
+        if (end > i) {
+            if (data[i] == '>') {
+                if (recs == max_records) return -1;
+                seq_offs[recs] = o;
+                int64_t s = i + 1;
+                while (s < end && fa_blank(data[s])) ++s;
+                int64_t e = s;
+                while (e < end && !fa_blank(data[e])) ++e;
+                name_span[2 * recs] = s;
+                name_span[2 * recs + 1] = e;
+                ++recs;
+            } else if (recs > 0) {
+                int64_t a2 = i, b2 = end;
+                while (a2 < b2 && fa_blank(data[a2])) ++a2;
+                while (b2 > a2 && fa_blank(data[b2 - 1])) --b2;
+                if (map_acgtn) {
+                    for (int64_t k = a2; k < b2; ++k) out[o + (k - a2)] = tab[data[k]];
+                } else {
+                    std::memcpy(out + o, data + a2, (size_t)(b2 - a2));
+                }
+                o += b2 - a2;
+            }
+        }
+        i = next;
+    }
+    seq_offs[recs] = o;
+    return recs;
+}

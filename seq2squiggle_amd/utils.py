@@ -72,9 +72,47 @@ def _open_text(path):
     return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
 
 
+def _read_fasta_native(path, map_acgtn: bool = False):
+    """Plain (not gzipped) FASTA files through the library's host-side parser (s2s_fasta_clean): the same (sequence, name)
+    pairs as the line loop of read_fasta -- with map_acgtn also process_genome's upper-casing and non-ACGT -> N -- without the
+    interpreter touching a line (a 100 Mb reference: 0.1 s instead of 0.7 s, which every rank of a sharded run pays before its
+    first kernel).  None: not applicable (FASTQ, gzip, library not built), the caller falls back to the line loop."""
+    path = str(path)
+    try:
+        if path.endswith(".gz"):
+            return None
+        size = os.path.getsize(path)
+        if size == 0:
+            return []
+        from ._lib import lib
+        L = lib()
+        data = np.memmap(path, dtype=np.uint8, mode="r")
+    except Exception:
+        return None
+    n_rec = int(L.s2s_fasta_count(data.ctypes.data, size))
+    if n_rec < 0:
+        return None                          # FASTQ (or something else): the line loop decides
+    out = np.empty(size, np.uint8)
+    seq_offs = np.zeros(n_rec + 1, np.int64)
+    names = np.zeros(2 * n_rec + 2, np.int64)
+    got = int(L.s2s_fasta_clean(data.ctypes.data, size, 1 if map_acgtn else 0, out.ctypes.data, seq_offs.ctypes.data,
+                                names.ctypes.data, n_rec))
+    if got != n_rec:
+        return None
+    recs = []
+    for r in range(n_rec):
+        recs.append((out[seq_offs[r]:seq_offs[r + 1]].tobytes().decode("latin-1"),
+                     data[names[2 * r]:names[2 * r + 1]].tobytes().decode("latin-1")))
+    return recs
+
+
 def read_fasta(path: str, rna: bool = False) -> Generator[Tuple[str, str], None, None]:
     """(sequence, name) for every FASTA or FASTQ record (reference: pysam.FastxFile, utils.py:290-308).
     name = header up to the first whitespace, as pysam's `entry.name`; multi-line FASTA is joined."""
+    fast = _read_fasta_native(path)
+    if fast is not None:
+        yield from fast
+        return
     with _open_text(path) as fh:
         name, seq, mode = None, [], None
         it = iter(fh)
@@ -428,7 +466,8 @@ def process_genome(genome_seq: str):
 
 
 def preprocess_genome(fasta: str):
-    results = [process_genome(seq) for seq, _ in read_fasta(fasta)]
+    fast = _read_fasta_native(fasta, map_acgtn=True)          # parse + process_genome in one native pass
+    results = [(seq, len(seq)) for seq, _ in fast] if fast is not None else [process_genome(seq) for seq, _ in read_fasta(fasta)]
     if not results:
         raise ValueError(f"{fasta}: no sequences found")
     seqs, lens = zip(*results)

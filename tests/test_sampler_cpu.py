@@ -166,3 +166,56 @@ def test_native_replay_equals_the_interpreter_draw_for_draw(profile, r, n_frac, 
     # cases the native path must decline (-> None): another length law, a seed beyond the scipy fast range
     assert U.replay_sampler(n, seqs, lens, r, seed, total, "gamma", profile, min_len) is None
     assert U.replay_sampler(n, seqs, lens, r, 2 ** 32 - 100, total, "expon", profile, min_len) is None
+
+
+def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
+    """utils.read_fasta / preprocess_genome take plain FASTA files through the library's host-side parser (s2s_fasta_count /
+    s2s_fasta_clean); the records must be those of the interpreter's line loop (pysam.FastxFile semantics, utils.py:290-308, and
+    process_genome, 594-597) on well-formed and odd inputs alike; FASTQ and gzip keep the line loop."""
+    import gzip
+    from seq2squiggle_amd import utils as U
+
+    def both(path):
+        res = []
+        for native in (True, False):
+            if not native:
+                monkeypatch.setattr(U, "_read_fasta_native", lambda p, map_acgtn=False: None)
+            try:
+                res.append((list(U.read_fasta(path)), U.preprocess_genome(path)))
+            except Exception as e:
+                res.append(("raised", type(e).__name__))
+            monkeypatch.undo()
+        return res
+    cases = {
+        "plain": ">a desc here\nACGT\nacgtn\n>b\n\nGG\n>c\n", "crlf": ">a x\r\nACGT\r\nAC\r\n>b\r\nTT\r\n", "lead": "\n\n>a\nAC\n",
+        "junk_before": "hello\n>a\nAC\n>b\nGT", "spaces": ">a\n ACGT \nAC GT\t\n>b  \nTT\n", "empty": "", "blank": "\n\n",
+        "noname": ">\nACGT\n> \nGG\n", "gt_inside": ">a\nAC>GT\n>b\nTT\n", "fastq": "@q1\nACGT\n+\nIIII\n",
+        "no_final_newline": ">a\nACGT", "only_header": ">a", "iupac": ">a\nACGTRYKMnnxx-*\n", "tabname": ">a\tdesc\nAC\n",
+        "indent_header": "  >a\nAC\n", "blank_first": "  \n>a\nAC\n", "cr_only_lines": ">a\r\n\r\nAC\r\r\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / f"{name}.fa"
+        p.write_text(text, encoding="latin-1", newline="")
+        native, loop = both(str(p))
+        assert native == loop, (name, native, loop)
+    for f in ("example_test.fasta", "example_lambda_genome.fasta"):
+        native, loop = both(os.path.join(GOLDEN, f))
+        assert native == loop and native[0] != "raised"
+    rng = np.random.default_rng(0)
+    for it in range(40):
+        text = ""
+        for i in range(int(rng.integers(1, 6))):
+            L, w = int(rng.integers(0, 500)), int(rng.integers(1, 90))
+            s = "".join(rng.choice(list("ACGTNacgtRY"), L))
+            text += f">r{i} d{it}\n" + "".join(s[j:j + w] + ("\r\n" if it % 2 else "\n") for j in range(0, L, w)) + ("\n" if it % 3 == 0 else "")
+        p = tmp_path / "rand.fa"
+        p.write_text(text, newline="")
+        native, loop = both(str(p))
+        assert native == loop
+    # the native path is really taken for plain FASTA, and not for gzip / FASTQ
+    assert U._read_fasta_native(os.path.join(GOLDEN, "example_test.fasta")) is not None
+    gz = tmp_path / "x.fa.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(">a\nACGT\n")
+    assert U._read_fasta_native(str(gz)) is None and list(U.read_fasta(str(gz))) == [("ACGT", "a")]
+    assert U._read_fasta_native(str(tmp_path / "fastq.fa")) is None
