@@ -18,7 +18,8 @@ int main(int argc, char** argv) {
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
     const char* names[] = {"s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
                            "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_diag_read",
-                           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay"};
+                           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_fasta_count",
+                           "s2s_fasta_clean"};
     for (unsigned i = 0; i < sizeof names / sizeof *names; ++i)
         if (!dlsym(lib, names[i])) { fprintf(stderr, "missing symbol %s\n", names[i]); return 4; }
     blob_floats_fn blob_floats = (blob_floats_fn)dlsym(lib, "s2s_blob_floats");
@@ -64,6 +65,20 @@ int main(int argc, char** argv) {
     if (replay(mt, ends, 1, 0, 0, 5, 0, 100, 42, 1000, 1, 30, 20, -1, lens, &next_i) != 5 || next_i != 5 || mt[624] >= 624) return 14;
     for (int i = 0; i < 5; ++i) if (lens[i] < 30 || lens[i] > 1000) return 15;
     if (replay(mt, ends, 1, 0, 0, 5, 0, 0, 42, 1000, 1, 30, 20, -1, lens, &next_i) != S2S_ERR_ARG) return 16;   /* r must be > 0 */
+    /* the FASTA parser from plain C: two records, CRLF line ends, lower case and an ambiguity code mapped by process_genome's rule */
+    typedef int64_t (*fcount_fn)(const uint8_t*, int64_t);
+    typedef int64_t (*fclean_fn)(const uint8_t*, int64_t, int32_t, uint8_t*, int64_t*, int64_t*, int64_t);
+    fcount_fn fcount = (fcount_fn)dlsym(lib, "s2s_fasta_count");
+    fclean_fn fclean = (fclean_fn)dlsym(lib, "s2s_fasta_clean");
+    const char fa[] = ">chr1 first\r\nACgt\r\nnR\r\n>c2\nTT\n";
+    const int64_t fa_n = (int64_t)sizeof fa - 1;
+    uint8_t seqs[64];
+    int64_t so[3], ns[4];
+    if (fcount((const uint8_t*)fa, fa_n) != 2) return 17;
+    if (fclean((const uint8_t*)fa, fa_n, 1, seqs, so, ns, 2) != 2 || so[0] != 0 || so[1] != 6 || so[2] != 8) return 18;
+    if (memcmp(seqs, "ACGTNNTT", 8) != 0 || ns[1] - ns[0] != 4 || memcmp(fa + ns[0], "chr1", 4) != 0 || memcmp(fa + ns[2], "c2", 2) != 0) return 19;
+    if (fclean((const uint8_t*)fa, fa_n, 0, seqs, so, ns, 1) != -1) return 20;                        /* more records than room */
+    if (fcount((const uint8_t*)"@q\nAC\n+\nII\n", 11) != -2) return 21;                              /* FASTQ: not for this parser */
     printf("CABI_OK %zu\n", n);
     return 0;
 }
