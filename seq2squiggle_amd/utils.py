@@ -76,7 +76,7 @@ def _read_fasta_native(path, map_acgtn: bool = False):
     """Plain (not gzipped) FASTA files through the library's host-side parser (s2s_fasta_clean): the same (sequence, name)
     pairs as the line loop of read_fasta -- with map_acgtn also process_genome's upper-casing and non-ACGT -> N -- without the
     interpreter touching a line (a 100 Mb reference: 0.1 s instead of 0.7 s, which every rank of a sharded run pays before its
-    first kernel).  None: not applicable (FASTQ, gzip, library not built), the caller falls back to the line loop."""
+    first kernel).  None: not applicable (FASTQ, gzip, files over 4 GB, library not built), the caller falls back to the line loop."""
     path = str(path)
     try:
         if path.endswith(".gz"):
@@ -84,6 +84,8 @@ def _read_fasta_native(path, map_acgtn: bool = False):
         size = os.path.getsize(path)
         if size == 0:
             return []
+        if size > int(os.environ.get("S2S_FASTA_NATIVE_LIMIT", 4 << 30)):
+            return None                      # the records of this path are all in memory at once: larger files keep the streaming loop
         from ._lib import lib
         L = lib()
         data = np.memmap(path, dtype=np.uint8, mode="r")

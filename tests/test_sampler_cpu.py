@@ -219,3 +219,5 @@ def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
         f.write(">a\nACGT\n")
     assert U._read_fasta_native(str(gz)) is None and list(U.read_fasta(str(gz))) == [("ACGT", "a")]
     assert U._read_fasta_native(str(tmp_path / "fastq.fa")) is None
+    monkeypatch.setenv("S2S_FASTA_NATIVE_LIMIT", "10")                      # larger files stream through the line loop
+    assert U._read_fasta_native(os.path.join(GOLDEN, "example_test.fasta")) is None
