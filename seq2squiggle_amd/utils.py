@@ -72,7 +72,7 @@ def _open_text(path):
     return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
 
 
-def _read_fasta_native(path, map_acgtn: bool = False):
+def _read_fasta_native(path, map_acgtn: bool = False, limit: int = 4 << 30):
     """Plain (not gzipped) FASTA files through the library's host-side parser (s2s_fasta_clean): the same (sequence, name)
     pairs as the line loop of read_fasta -- with map_acgtn also process_genome's upper-casing and non-ACGT -> N -- without the
     interpreter touching a line (a 100 Mb reference: 0.1 s instead of 0.7 s, which every rank of a sharded run pays before its
@@ -84,7 +84,7 @@ def _read_fasta_native(path, map_acgtn: bool = False):
         size = os.path.getsize(path)
         if size == 0:
             return []
-        if size > int(os.environ.get("S2S_FASTA_NATIVE_LIMIT", 4 << 30)):
+        if size > int(os.environ.get("S2S_FASTA_NATIVE_LIMIT", limit)):
             return None                      # the records of this path are all in memory at once: larger files keep the streaming loop
         from ._lib import lib
         L = lib()
@@ -111,8 +111,8 @@ def _read_fasta_native(path, map_acgtn: bool = False):
 def read_fasta(path: str, rna: bool = False) -> Generator[Tuple[str, str], None, None]:
     """(sequence, name) for every FASTA or FASTQ record (reference: pysam.FastxFile, utils.py:290-308).
     name = header up to the first whitespace, as pysam's `entry.name`; multi-line FASTA is joined."""
-    fast = _read_fasta_native(path)
-    if fast is not None:
+    fast = _read_fasta_native(path, limit=256 << 20)     # read files stream (line loop below) unless they are small; references
+    if fast is not None:                                  # (preprocess_genome) are held whole anyway and go native up to 4 GB
         yield from fast
         return
     with _open_text(path) as fh:

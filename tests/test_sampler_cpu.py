@@ -179,7 +179,7 @@ def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
         res = []
         for native in (True, False):
             if not native:
-                monkeypatch.setattr(U, "_read_fasta_native", lambda p, map_acgtn=False: None)
+                monkeypatch.setattr(U, "_read_fasta_native", lambda p, map_acgtn=False, limit=0: None)
             try:
                 res.append((list(U.read_fasta(path)), U.preprocess_genome(path)))
             except Exception as e:
