@@ -400,31 +400,51 @@ def _check_sampling_args(n, r, c):
         raise ValueError("You need to specify the read length r")
 
 
+_REPLAY_BLOCK = 8192
+
+
 def sample_read_shard(genome_seqs, genome_lens, n, r, c, seed, distr, profile, min_read_len, shard_of):
     """One rank's share of the read set sample_reads_from_reference would draw: pass 1 replays the sampler for the read
     LENGTHS only, `shard_of(lengths)` -> (lo, hi) picks the rank's contiguous range, pass 2 moves the `random` generator in
     front of read lo, then the rank's reads are built lazily (the predict loop pulls them while it packs batches) and the
     iterator stops behind read hi-1.  Both replays run in native code when the reference's default length law is in use
-    (replay_sampler: ~25 ns per read instead of 4.3 us -- 300,000 reads of BASELINE configs[4]: 15 ms instead of 1.3 s per pass,
-    which every rank pays before its first kernel); otherwise in the interpreter, draw for draw.
+    (replay_sampler: ~1 us per read -- most of it seeding scipy's per-read generator -- instead of 7 in the interpreter; 300,000
+    reads of BASELINE configs[4]: 0.3 s, which every rank pays before its first kernel; pass 2 costs at most one block);
+    otherwise in the interpreter, draw for draw.
     -> (iterator over reads lo..hi-1 as (seq, uuid) pairs, all read lengths)."""
     _check_sampling_args(n, r, c)
     total_len = sum(len(seq) for seq in genome_seqs)
     seq_num = n if n != -1 else round(c * total_len / r)
     state = random.getstate()
     cache = {}
-    fast = replay_sampler(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, _cache=cache)
-    if fast is not None:
-        lens = fast[0].tolist()
-    else:
+    # pass 1 in blocks of _REPLAY_BLOCK accepted reads, the generator state kept in front of every block: pass 2 then starts at
+    # the block that holds read lo instead of at read 0 (the last rank of eight would replay 7/8 of the run a second time)
+    marks, lens, acc, nxt, native = [], [], 0, 0, True
+    while nxt < seq_num:
+        marks.append((acc, nxt, random.getstate()))
+        got = replay_sampler(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
+                             first_read_i=nxt, stop_after=_REPLAY_BLOCK, _cache=cache)
+        if got is None:
+            native = False
+            break
+        lens.extend(got[0].tolist())
+        acc += len(got[0])
+        nxt = got[1]
+    if not native:
+        random.setstate(state)
         lens = sampling(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len, materialise=(0, 0))
     lo, hi = shard_of(lens)
     random.setstate(state)
     start_i, start_acc = 0, 0
-    if fast is not None and lo > 0:
-        skipped = replay_sampler(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
-                                 stop_after=lo, want_lengths=False, _cache=cache)
-        start_i, start_acc = skipped[1], lo
+    if native and lo > 0:
+        acc0, nxt0, st0 = max((m for m in marks if m[0] <= lo), key=lambda m: m[0])
+        random.setstate(st0)
+        start_i = nxt0
+        if lo > acc0:
+            skipped = replay_sampler(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,
+                                     first_read_i=nxt0, stop_after=lo - acc0, want_lengths=False, _cache=cache)
+            start_i = skipped[1]
+        start_acc = lo
 
     def own_reads():
         it = sampling_iter(seq_num, genome_seqs, genome_lens, r, seed, total_len, distr, profile, min_read_len,

@@ -100,11 +100,14 @@ def test_profiles_match_reference_table():
     assert p["sample_rate"] == 4000 and p["bps"] == 400
 
 
+@pytest.mark.parametrize("block", [8192, 7])
 @pytest.mark.parametrize("world", [1, 3, 8])
-def test_sharded_sampling_equals_slices_of_the_full_read_set(world):
+def test_sharded_sampling_equals_slices_of_the_full_read_set(world, block, monkeypatch):
     """sample_read_shard (lengths-only replay + strings for one range) gives every rank exactly its slice of the read set
-    the unsharded sampler draws for the same seed, including reads with N (extra `random` draws) and rejected tries."""
+    the unsharded sampler draws for the same seed, including reads with N (extra `random` draws) and rejected tries; also when
+    the replay runs in several blocks and a rank resumes from the generator state kept in front of the block of its first read."""
     from seq2squiggle_amd.parallel import shard_reads
+    monkeypatch.setattr(U, "_REPLAY_BLOCK", block)
     rng = np.random.default_rng(3)
     contig2 = "".join(rng.choice(list("ACGTN"), 20000, p=[.24, .24, .24, .24, .04]))
     seqs, lens = zip(*[U.process_genome(s) for s in (next(iter(U.read_fasta(LAMBDA)))[0][:30000], contig2)])
