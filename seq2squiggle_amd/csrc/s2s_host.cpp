@@ -560,18 +560,15 @@ inline uint32_t mt_temper(uint32_t y) {
 // draw_expon_dis(mean = r, seed): scipy's expon.rvs(loc, scale, size = 1, random_state = seed) builds np.random.RandomState(seed)
 // (init_genrand) and takes loc + scale * -log(1 - random_sample()); then int(x * r / 7106), clipped to [1, total_len]
 // (reference utils.py:325-331).  Only the generator's first two outputs are needed: state words 0-2, 397, 398.
+struct MtWords { uint32_t w0, w1, w2, w397, w398; };
+
 #pragma clang fp contract(off)
-int64_t expon_length(uint32_t seed, double r, int64_t total_len) {
-    uint32_t x = seed, w0 = seed, w1 = 0, w2 = 0, w397 = 0, w398 = 0;
-    for (uint32_t i = 1; i < 399; ++i) {
-        x = 1812433253u * (x ^ (x >> 30)) + i;
-        if (i == 1) w1 = x; else if (i == 2) w2 = x; else if (i == 397) w397 = x; else if (i == 398) w398 = x;
-    }
+int64_t expon_from_words(const MtWords& w, double r, int64_t total_len) {
     auto twist = [](uint32_t a, uint32_t b, uint32_t c) {
         const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
         return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     };
-    const uint32_t a = mt_temper(twist(w0, w1, w397)) >> 5, b = mt_temper(twist(w1, w2, w398)) >> 6;
+    const uint32_t a = mt_temper(twist(w.w0, w.w1, w.w397)) >> 5, b = mt_temper(twist(w.w1, w.w2, w.w398)) >> 6;
     const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     const double e = -std::log(1.0 - u);
     const double loc = 213.98910256668592, scale = 6972.5319847131141, fitted_mean = 7106.0;
@@ -583,6 +580,35 @@ int64_t expon_length(uint32_t seed, double r, int64_t total_len) {
     if (n < 1) n = 1;
     if (n > total_len) n = total_len;
     return n;
+}
+
+int64_t expon_length(uint32_t seed, double r, int64_t total_len) {
+    uint32_t x = seed;
+    MtWords w{seed, 0, 0, 0, 0};
+    for (uint32_t i = 1; i < 399; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + i;
+        if (i == 1) w.w1 = x; else if (i == 2) w.w2 = x; else if (i == 397) w.w397 = x; else if (i == 398) w.w398 = x;
+    }
+    return expon_from_words(w, r, total_len);
+}
+
+// The seeding recurrence is a serial chain of 398 multiplies per seed (0.5 us): eight seeds at a time fill the lanes of one AVX2
+// register (the first tries of eight consecutive reads; retries stay scalar).  Same integer arithmetic, lane by lane.
+#define S2S_MT_WORDS8_BODY                                                                          \
+    uint32_t x[8];                                                                                  \
+    for (int l = 0; l < 8; ++l) { x[l] = seeds[l]; out[l].w0 = seeds[l]; }                          \
+    for (uint32_t i = 1; i < 399; ++i) {                                                            \
+        for (int l = 0; l < 8; ++l) x[l] = 1812433253u * (x[l] ^ (x[l] >> 30)) + i;                 \
+        if (i == 1) { for (int l = 0; l < 8; ++l) out[l].w1 = x[l]; }                               \
+        else if (i == 2) { for (int l = 0; l < 8; ++l) out[l].w2 = x[l]; }                          \
+        else if (i == 397) { for (int l = 0; l < 8; ++l) out[l].w397 = x[l]; }                      \
+        else if (i == 398) { for (int l = 0; l < 8; ++l) out[l].w398 = x[l]; }                      \
+    }
+__attribute__((target("avx2"))) void mt_words8_avx2(const uint32_t* seeds, MtWords* out) { S2S_MT_WORDS8_BODY }
+void mt_words8_plain(const uint32_t* seeds, MtWords* out) { S2S_MT_WORDS8_BODY }
+void mt_words8(const uint32_t* seeds, MtWords* out) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !std::getenv("S2S_NO_AVX2");      // (the variable: tests of the plain path)
+    if (avx2) mt_words8_avx2(seeds, out); else mt_words8_plain(seeds, out);
 }
 
 }  // namespace
@@ -598,14 +624,24 @@ extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_
     if (seed + (uint64_t)num_seqs * (uint64_t)(max_retries + 1) >= (1ull << 32)) return S2S_ERR_ARG;   // (the scipy seed must not wrap)
     Mt19937 g{mt_state, mt_state[624]};
     int64_t accepted = 0, read_i = first_read_i;
+    int64_t first_try[8], first_base = -1;                    // lengths of the first tries of reads first_base .. first_base + 7
     for (; read_i < num_seqs && (stop_after < 0 || accepted < stop_after); ++read_i) {
+        if (first_base < 0 || read_i >= first_base + 8) {
+            uint32_t seeds[8];
+            MtWords w[8];
+            for (int l = 0; l < 8; ++l) seeds[l] = (uint32_t)(seed + (uint64_t)(read_i + l) * (uint64_t)(max_retries + 1));
+            mt_words8(seeds, w);
+            for (int l = 0; l < 8; ++l) first_try[l] = expon_from_words(w[l], (double)r, total_len);
+            first_base = read_i;
+        }
         for (int retry = 0; retry < max_retries; ++retry) {
             const int64_t pos = (int64_t)g.below((uint64_t)genome);                 // random.randint(0, total_genome_len - 1)
             const int64_t* ce = std::upper_bound(contig_ends, contig_ends + n_contigs, pos);   // bisect_right
             const int where = (int)(ce - contig_ends);
             const int64_t start = where ? contig_ends[where - 1] : 0, offset = pos - start, clen = contig_ends[where] - start;
-            const int64_t length = expon_length((uint32_t)(seed + (uint64_t)read_i * (uint64_t)(max_retries + 1) + (uint64_t)retry),
-                                                (double)r, total_len);
+            const int64_t length = retry == 0 ? first_try[read_i - first_base]
+                                              : expon_length((uint32_t)(seed + (uint64_t)read_i * (uint64_t)(max_retries + 1) + (uint64_t)retry),
+                                                             (double)r, total_len);
             const int64_t got = std::min(length, clen - offset);                     // genome[offset : offset + length]
             if (is_dna) (void)g.below(2);                                           // random.choice("+-")
             if (is_dna && got != length) continue;                                  // read_check: end-of-contig rejection

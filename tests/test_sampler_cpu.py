@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from seq2squiggle_amd import utils as U
-from conftest import GOLDEN, load_npz
+from conftest import GOLDEN, ROOT, load_npz
 
 LAMBDA = os.path.join(GOLDEN, "example_lambda_genome.fasta")
 
@@ -224,3 +224,28 @@ def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
     assert U._read_fasta_native(str(tmp_path / "fastq.fa")) is None
     monkeypatch.setenv("S2S_FASTA_NATIVE_LIMIT", "10")                      # larger files stream through the line loop
     assert U._read_fasta_native(os.path.join(GOLDEN, "example_test.fasta")) is None
+
+
+def test_native_replay_without_avx2_takes_the_same_draws():
+    """The replay's eight-seeds-at-a-time seeding has an AVX2 and a plain build of the same loop; S2S_NO_AVX2 selects the plain
+    one (a process-wide choice, hence the child process): both must give the interpreter's lengths and generator state."""
+    import subprocess, sys
+    code = r"""
+import random, sys
+sys.path.insert(0, %r)
+import numpy as np
+from seq2squiggle_amd import utils as U
+rng = np.random.default_rng(2)
+seqs = ["".join(rng.choice(list("ACGT"), L)) for L in (30000, 9000)]
+lens = [len(s) for s in seqs]
+random.seed(3)
+want = [len(x) if isinstance(x, str) else x for x in U.sampling(300, seqs, lens, 2500, 3, sum(lens), "expon", "dna-r10-prom", 30, materialise=(0, 0))]
+state_after = random.getstate()
+random.seed(3)
+got = U.replay_sampler(300, seqs, lens, 2500, 3, sum(lens), "expon", "dna-r10-prom", 30)
+assert got is not None and got[0].tolist() == want and random.getstate() == state_after
+print("REPLAY_OK", len(want))
+""" % ROOT
+    for extra in ({}, {"S2S_NO_AVX2": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **extra), timeout=300)
+        assert "REPLAY_OK" in r.stdout, r.stdout + r.stderr[-2000:]
