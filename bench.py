@@ -81,7 +81,8 @@ def _e2e_dirs():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
 
-def _e2e_run(mode, n_reads, ext="blow5", where="default", fasta=None, r=5000, c=-1):
+def _e2e_run(mode, n_reads, ext="blow5", where="default", fasta=None, r=5000, c=-1, ckpt="synthetic_k9.ckpt",
+             profile="dna-r10-prom", noise_std=2.0):
     """One inference_run (FASTA -> container file in a fresh temporary directory) -> (seconds, chunks, output bytes)."""
     import tempfile
     from seq2squiggle_amd.cli import set_config
@@ -92,9 +93,9 @@ def _e2e_run(mode, n_reads, ext="blow5", where="default", fasta=None, r=5000, c=
         out = os.path.join(td, "o." + ext)
         set_seeds(42)
         t0 = time.perf_counter()
-        m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"),
-                          fasta=fasta, read_input=False, n=n_reads, r=r, c=c, out=out, profile="dna-r10-prom",
-                          dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
+        m = inference_run(config=set_config(None), saved_weights=os.path.join(ROOT, "tests", "golden", ckpt),
+                          fasta=fasta, read_input=False, n=n_reads, r=r, c=c, out=out, profile=profile,
+                          dwell_mean=None, dwell_std=0.0, noise_std=noise_std, noise_sampling=True, duration_sampling=True,
                           distr="expon", predict_batch_size=1024, export_every_n_samples=1000000, sample_rate=None,
                           bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
                           median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
@@ -124,12 +125,15 @@ def end_to_end(mode):
     import tempfile
     out_dir = _e2e_dirs()
 
-    def run(n_reads, ext="blow5", where=out_dir, fasta=None, r=5000, c=-1):
-        return _e2e_run(mode, n_reads, ext, where, fasta, r, c)
+    def run(n_reads, ext="blow5", where=out_dir, fasta=None, r=5000, c=-1, **kw):
+        return _e2e_run(mode, n_reads, ext, where, fasta, r, c, **kw)
     first, _, _ = run(1000)            # the first call also pays the process's one-time costs (pinned buffers, thread pools)
     warm = [run(1000) for _ in range(3)]                # host-side timing moves by several ms from call to call: median of three
     el, chunks, size = sorted(warm)[1]
     el3, chunks3, size3 = run(12500)
+    # BASELINE.json configs[3] ("dna_r9_min profile -n 100000 -r 8000 --noise-std 1.5", k = 6: utils.py:257-260): one GPU's share
+    run(1000, r=8000, ckpt="synthetic_k6.ckpt", profile="dna-r9-min", noise_std=1.5)
+    el4, chunks4, size4 = run(12500, r=8000, ckpt="synthetic_k6.ckpt", profile="dna-r9-min", noise_std=1.5)
     run(1000, "pod5")
     warm_p = [run(1000, "pod5") for _ in range(3)]
     elp, chunksp, sizep = sorted(warm_p)[1]
@@ -162,6 +166,10 @@ def end_to_end(mode):
             "config3_share": {"workload": "example lambda genome -n 12500 -r 5000 -> .blow5: one GPU's share of configs[2]",
                               "seconds": el3, "reads_per_sec": 12500 / el3, "chunks": chunks3, "chunks_per_sec": chunks3 / el3,
                               "output_bytes": size3},
+            "config4_share": {"workload": "example lambda genome -n 12500 -r 8000 --profile dna-r9-min --noise-std 1.5 (k = 6 checkpoint) "
+                                          "-> .blow5: one GPU's share of BASELINE configs[3]",
+                              "seconds": el4, "reads_per_sec": 12500 / el4, "chunks": chunks4, "chunks_per_sec": chunks4 / el4,
+                              "output_bytes": size4},
             "pod5": {"workload": "configs[1]'s reads -> .pod5 (VBZ signal rows: svb16 on the GPU, zstd on host threads), the "
                                  "container BASELINE configs[4] asks for", "seconds": elp, "reads_per_sec": 1000 / elp,
                      "chunks": chunksp, "chunks_per_sec": chunksp / elp, "output_bytes": sizep},
@@ -213,6 +221,79 @@ def reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, steps):
            "parity": parity_vs_oracle(sd, cfg, eng), "tolerance_note": "outside the 1e-4 pA parity bound by design"}
     eng.close()
     return out
+
+
+FLOP_PER_CHUNK_K6 = 85_052_672         # k = 6: the embedding gather takes 6 columns instead of 9, everything else is the same
+
+
+def _timed_steps(eng, bases_d, nv_d, sig, dur, params, steps):
+    """`steps` launches of the resident batch -> (chunks/s by wall, Engine.stats() of exactly those launches, kernel ms per launch)."""
+    eng.predict_chunks(bases_d, nv_d, params, out_signal=sig, out_dur=dur)
+    torch.cuda.synchronize()
+    eng.stats()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.predict_chunks(bases_d, nv_d, params, out_signal=sig, out_dur=dur)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eng.set_profiling(False)
+    ms, nl, _ = eng.kernel_ms()
+    return bases_d.shape[0] * steps / el, eng.stats(), (ms / nl if nl else None)
+
+
+def _stats_fields(st):
+    return {"softmax_redo_rate": st["redo_rate"], "in_kernel_clock_ghz": st["in_kernel_clock_ghz"],
+            "cycles_per_chunk_and_cu": st["cycles_per_chunk_and_cu"],
+            "attention_steps_hi_only_share": (st["steps_hi_only"] / st["steps_classified"]) if st["steps_classified"] else None,
+            "attention_steps_skipped_share": (st["steps_skipped"] / st["steps_classified"]) if st["steps_classified"] else None}
+
+
+def config4_k6_leg(mode, dev, steps):
+    """BASELINE.json configs[3]'s shape with inputs resident: the k = 6 chemistry (dna-r9-min, utils.py:257-260), 8 kb reads,
+    --noise-std 1.5 -- 625 reads x 500 chunks = 312,500 chunks per launch, synthetic k = 6 checkpoint -- with its own
+    roofline fraction and the kernel's own counters for those launches."""
+    sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k6.ckpt"))
+    eng = S.Engine(sd, cfg, device=dev.index, mode=mode)
+    rng = np.random.default_rng(4321)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [lut[c].tobytes().decode() for c in rng.integers(0, 4, size=(625, 8000), dtype=np.uint8)]
+    bases, nv, _ = S.encode_reads(reads, 6)
+    b, n = torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev)
+    sig = torch.empty(b.shape[0], 250, dtype=torch.float32, device=dev)
+    dur = torch.empty(b.shape[0], 16, dtype=torch.int32, device=dev)
+    rate, st, ms = _timed_steps(eng, b, n, sig, dur, S.PredictParams(seed=42, noise_std=1.5), steps)
+    eng.close()
+    tflops = FLOP_PER_CHUNK_K6 * b.shape[0] / (ms * 1e-3) / 1e12
+    return {"workload": "625 synthetic reads x 8000 nt (312,500 chunks per launch), k = 6 checkpoint, noise_std 1.5, default samplers",
+            "chunks_per_sec": rate, "reads_per_sec": rate / 500, "samples_per_sec": rate * 250, "avg_launch_ms": ms,
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK[mode], "unit": "TFLOP/s", "frac": tflops / PEAK[mode],
+                         "flop_per_chunk": FLOP_PER_CHUNK_K6}, **_stats_fields(st)}
+
+
+def weight_sensitivity_leg(mode, bases_d, nv_d, sig, dur, params, steps):
+    """How the headline moves with the WEIGHTS.  No trained checkpoint exists offline (the reference downloads them,
+    inference.py:151-208), and this kernel is data dependent in two ways: the fast softmax path is redone on a safe path for
+    heads whose later keys beat the first 64 keys' maximum by more than the f16 range, and the chip's clock under the kernel
+    follows the operands.  Same workload as the headline, decoder w_qs / w_ks (weights and biases) of the committed k = 9
+    checkpoint scaled: x 1/3 is torch's default init, x 1 the committed checkpoint (the headline), x 4 and x 16 the sharpened
+    ones of tests/test_gpu_parity.py::test_peaked_attention_forces_the_rescale_fallback."""
+    sd0, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
+    rows = []
+    for scale, name in ((1.0 / 3.0, "default init (committed / 3)"), (1.0, "committed synthetic_k9.ckpt (headline)"),
+                        (4.0, "committed x 4"), (16.0, "committed x 16")):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for k in sd:
+            if k.startswith("decoders.") and k.endswith(("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")):
+                sd[k] *= scale
+        eng = S.Engine(sd, cfg, device=bases_d.device.index, mode=mode)
+        rate, st, ms = _timed_steps(eng, bases_d, nv_d, sig, dur, params, steps)
+        rows.append({"decoder_wq_wk_scale": scale, "checkpoint": name, "chunks_per_sec": rate, "avg_launch_ms": ms,
+                     "attention_path": getattr(eng, "attention_path", None), **_stats_fields(st)})
+        eng.close()
+    rates = [r["chunks_per_sec"] for r in rows]
+    return {"workload": "the headline's resident batch, decoder w_qs / w_ks scaled", "rows": rows,
+            "min_chunks_per_sec": min(rates), "max_chunks_per_sec": max(rates)}
 
 
 def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
@@ -440,6 +521,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    eng.stats()                                            # reset: the counters below are those of the timed launches
     eng.set_profiling(True)
     if dist:
         dist.barrier()
@@ -454,6 +536,7 @@ def main():
     el = time.perf_counter() - t0
     eng.set_profiling(False)
     dec_ms, dec_launches, dec_chunks = eng.kernel_ms()
+    live = eng.stats()
     ranks_seen, per_rank = 1, [B * a.steps / own]
     if dist:
         t = torch.tensor([el], dtype=torch.float64, device=red_dev or dev)
@@ -500,6 +583,12 @@ def main():
                 # the clock the chip held: GRBM_GUI_ACTIVE / 8 XCDs / kernel wall of the PMC pass (profiled runs clock lower), and the
                 # in-kernel s_memtime / s_memrealtime ratio of the un-profiled diagnostic build (cycles per chunk and CU beside it)
                 "effective_clock_ghz": pmc["effective_clock_ghz"], "in_kernel_clock": pmc["in_kernel_clock"],
+                # LIVE, from the kernel's own counters over exactly the timed launches of this run (s2s_stats_read):
+                "live": {"in_kernel_clock_ghz": live["in_kernel_clock_ghz"], "cycles_per_chunk_and_cu": live["cycles_per_chunk_and_cu"],
+                         "softmax_redo_rate": live["redo_rate"], "softmax_runs": live["softmax_runs"],
+                         "source": "s_memtime / s_memrealtime of one thread per workgroup; redo counter of the fast softmax path"},
+                "pmc_note": "traffic, mfma_busy, valu_issue, effective_clock_ghz, in_kernel_clock: constants from the committed profiled passes "
+                            "named in traffic_source (another run, another device); `live` is this run",
                 "algorithmic_bytes_per_launch": 1088 * cpl if cpl else None,
                 "peak_note": {"f32": "f32-input MFMA peak (MI355X_MICROARCH.md)"}.get(
                     a.mode, "dense f16 MFMA peak (MI355X_MICROARCH.md); achieved counts ALGORITHMIC flops"),
@@ -548,6 +637,9 @@ def main():
             leg("cpu_baseline", cpu_baseline, sd, cfg, eng)
             if "value" in out["cpu_baseline"]:
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            leg("config4_k6", config4_k6_leg, a.mode, dev, a.steps)
+            if a.mode != "f32":
+                leg("weight_sensitivity", weight_sensitivity_leg, a.mode, bases_d, nv_d, sig, dur, params, max(2, min(a.steps, 5)))
             if a.mode == "f16x3":
                 leg("reduced_precision", reduced_precision_leg, sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
         sys.stdout.flush()

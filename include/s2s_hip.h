@@ -256,6 +256,18 @@ int64_t s2s_fasta_count(const uint8_t* data, int64_t n);
 int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
                         int64_t* name_span, int64_t max_records);
 
+/* Counters of the predict kernel since the last call (every build; synchronises the device, then resets them).  The fast
+ * softmax of the split-f16 decoder is data dependent -- a head whose later keys beat the first 64 keys' maximum by more than
+ * the f16 range is redone on a safe path -- and the chip's clock under this kernel depends on the operands, so a throughput
+ * figure is a statement about one set of weights: these counters say how a run behaved.  out10 =
+ *   [0] chunks launched, [1] (wave, head, layer) softmax runs (chunks x 8 waves x 8 heads x decoder layers),
+ *   [2] ... of them redone on the safe path (0 in S2S_MODE_F32, which has no fast path),
+ *   [3] shader-clock cycles (s_memtime) and [4] 100 MHz ticks (s_memrealtime) of one thread per workgroup over the whole
+ *       kernel, summed over [5] workgroups: [3] / [4] / 10 is the clock in GHz the SIMDs really ran at,
+ *   [6] 16-key attention steps run without the P_lo product, [7] skipped entirely, [8] classified in all (0 unless the
+ *       handle's tile classification is on: s2s_set_tile_classes), [9] reserved (0). */
+int s2s_stats_read(s2s_handle* h, uint64_t* out10);
+
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): per wave of a workgroup (8 rows) 48 per-phase shader-cycle sums
  * since the last call, summed over the workgroups (slots 0-15 decoder phases, 16-18 whole-kernel s_memtime / s_memrealtime /
  * wave count, 32-47 the frontend's own phases; tools/diag_phases.py names them); out384 = [8][48].  S2S_ERR_ARG in a normal build. */

@@ -42,7 +42,8 @@ struct ParamsDev {
 };
 struct DebugDev {
     float *emb_out, *enc_out, *sigma, *conc, *rate, *g, *y_scaled, *z01;
-    unsigned long long* diag;       // S2S_DIAG builds only
+    unsigned long long* diag;       // S2S_DIAG / S2S_TILEHIST builds only
+    unsigned long long* stats;      // every build: S2S_STAT_* counters of the handle (s2s_stats_read)
     const float *emb_in, *dec_in;   // stand-alone sub-module operators (TEST instance): stage INPUTS taken from memory
 };
 
@@ -84,6 +85,25 @@ __shared__ unsigned long long s2s_diag_lds[8 * S2S_DIAG_SLOTS];
 #define DIAG_DECL
 #define DIAG_STAMP(slot)
 #define DIAG_COUNT(slot, n)
+#endif
+
+// Production counters (every build, s2s_stats_read): a handful of LDS words per workgroup -- the heads whose fast softmax
+// overflowed and were redone on the safe path (counted INSIDE that rare branch: nothing on the fast path), and thread 0's
+// s_memtime / s_memrealtime at kernel entry -- folded into the handle's side buffer by one thread per workgroup when the kernel
+// ends (256 global atomics per launch).
+#define S2S_STAT_REDO 0          // (wave, head, layer) softmax runs that took the safe path
+#define S2S_STAT_CYCLES 1        // shader-clock cycles (s_memtime) of thread 0, summed over the workgroups
+#define S2S_STAT_TICKS 2         // 100 MHz ticks (s_memrealtime) over the same spans
+#define S2S_STAT_WGS 3           // workgroups summed
+#define S2S_STAT_TILES_HI 4      // attention tile classification (S2S_MODE_F16X3 with classification on): 16-key steps run without P_lo
+#define S2S_STAT_TILES_SKIP 5    //   ... skipped altogether
+#define S2S_STAT_TILES 6         //   ... classified in all
+__shared__ unsigned s2s_stats_lds[12];      // [0] redo, [1..3] tile classes (hi-only, skipped, all), [4..7] entry stamps
+
+#ifdef S2S_TILEHIST
+// diagnostic build: histogram of the largest shifted score (log2 units below the row's pass-0 maximum) per attention tile,
+// [decoder layer 0|1][32-key tile | 16-key step][64 bins of one unit; bin 63: above the pass-0 maximum]
+__shared__ unsigned s2s_hist_lds[2 * 2 * 64];
 #endif
 
 #ifndef S2S_ABL

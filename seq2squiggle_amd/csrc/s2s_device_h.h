@@ -344,7 +344,8 @@ __device__ __forceinline__ float sum_h(float v) {
 }
 template <int TV, bool SAFE, bool LO>
 __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
-                                             const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
+                                             const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O,
+                                             [[maybe_unused]] const int layer = 0) {
     constexpr int NT = 8;                                       // key tiles of 32
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto k_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp + 32 * t * 8); };
@@ -424,6 +425,27 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
                 for (int r = 0; r < 16; ++r) negm[r] = -mh;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm); // "score - m" from the matrix cores again
+            }
+#endif
+#ifdef S2S_TILEHIST
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float m16[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    float m = sc[i][8 * st];
+#pragma unroll
+                    for (int r = 1; r < 8; ++r) m = fmaxf(m, sc[i][8 * st + r]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                    m16[st] = m + S2S_SHIFT_BIAS;                  // relative to the row's pass-0 maximum
+                }
+                auto bin = [](const float t) { return t > 0.0f ? 63 : (-t >= 62.0f ? 62 : (int)(-t)); };
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&s2s_hist_lds[(layer * 2 + 0) * 64 + bin(fmaxf(m16[0], m16[1]))], 1u);
+                    atomicAdd(&s2s_hist_lds[(layer * 2 + 1) * 64 + bin(m16[0])], 1u);
+                    atomicAdd(&s2s_hist_lds[(layer * 2 + 1) * 64 + bin(m16[1])], 1u);
+                }
             }
 #endif
 #pragma unroll
@@ -650,7 +672,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     // SQ_LDS_BANK_CONFLICT count.)
                     const _Float16* vp = (n < 16 ? Vl + (head * 16 + n) * G::VS : n == 16 ? crow : (n >= 20 && n < 28 && !S2S_ONE_ZEROS_ROW) ? zrow2 : crow + G::VS) + 8 * hl;
                     f32x16 O;
-                    softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
+                    softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, kp2, vp, qb1, qb2, one, hl, O, pf_src ? 1 : 0);
                     float lsum = sum_h(O[8]);                              // row 16 lives in the lower lane half
 #if !S2S_ALWAYS_RESCALE && !defined(S2S_NO_FALLBACK)
                     {
@@ -659,6 +681,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                         DIAG_COUNT(11, 1ull); if (redo) DIAG_COUNT(10, 1ull);
 #endif
                         if (__builtin_expect(redo, 0)) {
+                            if (lane == 0) atomicAdd(&s2s_stats_lds[S2S_STAT_REDO], 1u);     // production counter (s2s_stats_read)
                             softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
                             lsum = sum_h(O[8]);
                         }
@@ -699,7 +722,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #ifdef S2S_DIAG
                     DIAG_COUNT(11, 1ull); if (redo) DIAG_COUNT(10, 1ull);
 #endif
-                    if (__builtin_expect(redo, 0)) softmax_pv<NQ, NKT, TV, true, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                    if (__builtin_expect(redo, 0)) {
+                        if (lane == 0) atomicAdd(&s2s_stats_lds[S2S_STAT_REDO], 1u);
+                        softmax_pv<NQ, NKT, TV, true, LO>(kp, vp, qb, ones, one, g, oH, oL, lH, lL);
+                    }
                 }
 #endif
 #pragma unroll

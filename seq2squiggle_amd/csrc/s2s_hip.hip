@@ -479,7 +479,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
     const float* const inj_zdw = TEST ? inj_zdw_ : nullptr;
     const float* const inj_z01 = TEST ? inj_z01_ : nullptr;
     DebugDev dbg = dbg_;
-    if (!TEST) { dbg = DebugDev{}; dbg.diag = dbg_.diag; }
+    if (!TEST) { dbg = DebugDev{}; dbg.diag = dbg_.diag; dbg.stats = dbg_.stats; }
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -489,6 +489,15 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         if (threadIdx.x < S2S_PROG_INTS + S2S_Z2_FLOATS)              // (and the second zeros row behind them)
             reinterpret_cast<int*>(lds_raw + DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS) * 4)[threadIdx.x] = 0;
     }
+    if (threadIdx.x == 0) {                // production counters: redo count, tile classes, entry stamps (kept in LDS, not in SGPRs, across the kernel)
+        const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+        s2s_stats_lds[0] = 0; s2s_stats_lds[1] = 0; s2s_stats_lds[2] = 0; s2s_stats_lds[3] = 0;
+        s2s_stats_lds[4] = (unsigned)c0; s2s_stats_lds[5] = (unsigned)(c0 >> 32);
+        s2s_stats_lds[6] = (unsigned)r0; s2s_stats_lds[7] = (unsigned)(r0 >> 32);
+    }
+#ifdef S2S_TILEHIST
+    for (int i = threadIdx.x; i < 2 * 2 * 64; i += DEC_WAVES * 64) s2s_hist_lds[i] = 0;
+#endif
 #ifdef S2S_DIAG
     for (int i = threadIdx.x; i < 8 * S2S_DIAG_SLOTS; i += DEC_WAVES * 64) s2s_diag_lds[i] = 0;
     const unsigned long long diag_c0 = __builtin_readcyclecounter(), diag_r0 = __builtin_amdgcn_s_memrealtime();
@@ -578,6 +587,23 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         for (int i = threadIdx.x; i < 8 * S2S_DIAG_SLOTS; i += DEC_WAVES * 64)
             if (s2s_diag_lds[i]) atomicAdd(dbg.diag + i, s2s_diag_lds[i]);        // [wave][slot], summed over the workgroups
 #endif
+    __syncthreads();                       // every wave's redo / tile counts are in LDS
+#ifdef S2S_TILEHIST
+    if (dbg.diag)
+        for (int i = threadIdx.x; i < 2 * 2 * 64; i += DEC_WAVES * 64)
+            if (s2s_hist_lds[i]) atomicAdd(dbg.diag + i, (unsigned long long)s2s_hist_lds[i]);
+#endif
+    if (threadIdx.x == 0 && dbg.stats) {
+        const unsigned long long c0 = ((unsigned long long)s2s_stats_lds[5] << 32) | s2s_stats_lds[4];
+        const unsigned long long r0 = ((unsigned long long)s2s_stats_lds[7] << 32) | s2s_stats_lds[6];
+        if (s2s_stats_lds[0]) atomicAdd(dbg.stats + S2S_STAT_REDO, (unsigned long long)s2s_stats_lds[0]);
+        if (s2s_stats_lds[1]) atomicAdd(dbg.stats + S2S_STAT_TILES_HI, (unsigned long long)s2s_stats_lds[1]);
+        if (s2s_stats_lds[2]) atomicAdd(dbg.stats + S2S_STAT_TILES_SKIP, (unsigned long long)s2s_stats_lds[2]);
+        if (s2s_stats_lds[3]) atomicAdd(dbg.stats + S2S_STAT_TILES, (unsigned long long)s2s_stats_lds[3]);
+        atomicAdd(dbg.stats + S2S_STAT_CYCLES, __builtin_readcyclecounter() - c0);
+        atomicAdd(dbg.stats + S2S_STAT_TICKS, __builtin_amdgcn_s_memrealtime() - r0);
+        atomicAdd(dbg.stats + S2S_STAT_WGS, 1ull);
+    }
 }
 
 // ================================================================================ export
@@ -814,7 +840,9 @@ struct s2s_handle {
     int* ws_svb = nullptr;            // s2s_svb_encode scratch: bytes per row
     int ws_svb_cap = 0;
     bool profiling = false;
-    unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: [8 waves][48] per-phase wave-cycle sums
+    unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: [8 waves][48] per-phase wave-cycle sums (S2S_TILEHIST: the tile histogram)
+    unsigned long long* d_stats = nullptr;  // S2S_STAT_* counters of the predict kernel (inside the slab; s2s_stats_read)
+    long long stat_chunks = 0;              // chunks launched since the last s2s_stats_read
     std::vector<EventPair> events;
     std::string err;
 };
@@ -1174,18 +1202,21 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
         const size_t o_counts = o_hand + up((size_t)h->n_wg * S2S_MAX_GROUP * S2S_SLOT_FLOATS * sizeof(float));
         const size_t o_offs = o_counts + up((size_t)cap * sizeof(int));
         const size_t o_svb = o_offs + up((size_t)cap * sizeof(long long));
-        h->slab_bytes = o_svb + up((size_t)rows * sizeof(int));
+        const size_t o_stats = o_svb + up((size_t)rows * sizeof(int));
+        h->slab_bytes = o_stats + 256;
         if ((e = hipMalloc(&h->slab, h->slab_bytes)) != hipSuccess) return bail(e, "hipMalloc(handle)");
         h->d_arena = reinterpret_cast<float*>(h->slab);
         h->handoff = reinterpret_cast<float*>(h->slab + o_hand);
         h->ws_counts = reinterpret_cast<int*>(h->slab + o_counts);
         h->ws_offs = reinterpret_cast<long long*>(h->slab + o_offs);
         h->ws_svb = reinterpret_cast<int*>(h->slab + o_svb);
+        h->d_stats = reinterpret_cast<unsigned long long*>(h->slab + o_stats);
         h->ws_export_cap = cap;
         h->ws_svb_cap = rows;
     }
     if ((e = hipMemcpy(h->d_arena, A.v.data(), h->arena_floats * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(arena)");
+    if ((e = hipMemset(h->d_stats, 0, 256)) != hipSuccess) return bail(e, "hipMemset(stats)");
     const struct { const void* fn; int bytes; } dyn_lds[] = {
         {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), Fused<0>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), Fused<1>::LDS},
         {reinterpret_cast<const void*>(s2s_fused_kernel<3, false>), Fused<3>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<0, true>), Fused<0>::LDS},
@@ -1193,7 +1224,7 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     for (const auto& k : dyn_lds)
         if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(dynamic LDS)");
-#ifdef S2S_DIAG
+#if defined(S2S_DIAG) || defined(S2S_TILEHIST)
     if ((e = hipMalloc(&h->d_diag, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
     if ((e = hipMemset(h->d_diag, 0, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
 #endif
@@ -1237,6 +1268,8 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
         D.emb_in = dbg->emb_in; D.dec_in = dbg->dec_in;
     }
     D.diag = h->d_diag;
+    D.stats = h->d_stats;
+    h->stat_chunks += B;
     const int nb = S2S_T_ENC + h->cfg.seq_kmer - 1;
     for (int64_t s = 0; s < B; s += h->tile) {
         const int n = (int)((B - s < h->tile) ? (B - s) : h->tile);
@@ -1393,6 +1426,23 @@ int s2s_get_kernel_ms(s2s_handle* h, double* ms_total, int64_t* launches, int64_
     if (ms_total) *ms_total = tot;
     if (launches) *launches = nl;
     if (chunks) *chunks = nc;
+    return S2S_OK;
+}
+
+int s2s_stats_read(s2s_handle* h, uint64_t* out10) {
+    if (!h || !out10) return S2S_ERR_ARG;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, S2S_ERR_HIP, "hipSetDevice failed");
+    HIP_TRY(h, hipDeviceSynchronize());
+    unsigned long long raw[8];
+    HIP_TRY(h, hipMemcpy(raw, h->d_stats, sizeof raw, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemset(h->d_stats, 0, sizeof raw));
+    out10[0] = (uint64_t)h->stat_chunks;
+    out10[1] = (uint64_t)h->stat_chunks * DEC_WAVES * S2S_HEADS * (uint64_t)h->cfg.decoder_layers;
+    out10[2] = raw[S2S_STAT_REDO];
+    out10[3] = raw[S2S_STAT_CYCLES]; out10[4] = raw[S2S_STAT_TICKS]; out10[5] = raw[S2S_STAT_WGS];
+    out10[6] = raw[S2S_STAT_TILES_HI]; out10[7] = raw[S2S_STAT_TILES_SKIP]; out10[8] = raw[S2S_STAT_TILES]; out10[9] = 0;
+    h->stat_chunks = 0;
     return S2S_OK;
 }
 

@@ -253,3 +253,16 @@ class Engine:
         ms, nl, nc = C.c_double(), C.c_int64(), C.c_int64()
         self._check(_lib.lib().s2s_get_kernel_ms(self._h, C.byref(ms), C.byref(nl), C.byref(nc)), "s2s_get_kernel_ms")
         return ms.value, nl.value, nc.value
+
+    def stats(self) -> dict:
+        """Counters of the predict kernel since the last call (s2s_stats_read; synchronises the device): how THIS run behaved --
+        the share of softmax runs redone on the safe path and the clock the SIMDs held are data dependent."""
+        out = (C.c_uint64 * 10)()
+        self._check(_lib.lib().s2s_stats_read(self._h, out), "s2s_stats_read")
+        chunks, runs, redo, cyc, ticks, wgs, t_hi, t_skip, t_all, _ = (int(x) for x in out)
+        return {"chunks": chunks, "softmax_runs": runs, "softmax_redone": redo,
+                "redo_rate": (redo / runs) if runs else 0.0,
+                "in_kernel_clock_ghz": (cyc / ticks * 0.1) if ticks else None,
+                "cycles_per_chunk_and_cu": (cyc / chunks) if chunks else None,    # a workgroup owns its CU: sum of their cycles / chunks
+                "shader_cycles": cyc, "ticks_100mhz": ticks, "workgroups": wgs,
+                "steps_hi_only": t_hi, "steps_skipped": t_skip, "steps_classified": t_all}

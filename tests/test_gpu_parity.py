@@ -207,9 +207,18 @@ def test_peaked_attention_forces_the_rescale_fallback(mode, scale):
     ref = O.predict_chunks(sd, cfg, g["codes"], O.PredictParams(**p), inject_g=torch.from_numpy(g["g"]), stages=True)
     ref64 = O.predict_chunks(sd, cfg, g["codes"], O.PredictParams(**p), inject_g=torch.from_numpy(g["g"]), dtype=torch.float64)
     eng = S.Engine(sd, cfg, mode=mode)
+    eng.stats()
     out = eng.predict_chunks(torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), S.PredictParams(**p),
                              inject_g=torch.from_numpy(g["g"]).cuda())
     y, r, t = out["signal"].cpu().numpy(), ref["signal"].numpy(), ref64["signal"].numpy()
+    st = eng.stats()                       # the production counters (s2s_stats_read) saw the rare branch
+    assert st["chunks"] == bases.shape[0] and st["softmax_runs"] == bases.shape[0] * 8 * 8 * 2
+    assert 1.0 < st["in_kernel_clock_ghz"] < 2.6 and st["workgroups"] == min(256, bases.shape[0])
+    if mode == "f16x3":
+        assert 0 < st["softmax_redone"] <= st["softmax_runs"], st
+    else:
+        assert st["softmax_redone"] == 0
+    assert eng.stats()["chunks"] == 0      # read-and-reset
     assert np.isfinite(y).all()
     same = ((y == 0) == (t == 0))
     assert same.mean() > 0.999
