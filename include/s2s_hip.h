@@ -256,6 +256,21 @@ int64_t s2s_fasta_count(const uint8_t* data, int64_t n);
 int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
                         int64_t* name_span, int64_t max_records);
 
+/* Which softmax path the split-f16 decoder attention (S2S_MODE_F16X3 / S2S_MODE_F16) tries first (layers.py:20-40 is one
+ * unmasked softmax over 250 keys; both paths compute it within the parity bound):
+ *   0  the FAST path: shift = the row's maximum over its first 64 keys + 2 log2 units, no maximum in later passes, straight-line
+ *      code; a head whose later keys beat that shift by more than the f16 range is detected by its row sum and redone by an
+ *      out-of-line online softmax (maximum and rescale in every pass).  Best for diffuse attention (the synthetic checkpoints: 0.006 - 2 % of the heads are redone);
+ *   1  the EXACT path at once: running row maximum, rows re-centred only when a new score beats it by more than 8 units, and
+ *      every 16-key step classified by its largest shifted score -- below -32 the step is skipped, below -16 it runs without
+ *      the P_lo halves.  More attention work than the fast path when nothing classifies, far less than "fast, then redo"
+ *      when most heads overflow (sharply peaked attention).  A kernel instance of its own.
+ * s2s_create chooses by a calibration launch on a fixed pseudo-random batch (exact when more than a quarter of its heads had to
+ * be redone; the environment variable S2S_ATTENTION_PATH=fast|exact skips the launch); `calibration_redo_rate` returns that
+ * share (-1 when no calibration ran).  Results are deterministic per chunk for a given path. */
+int s2s_set_attention_path(s2s_handle* h, int32_t path);
+int s2s_get_attention_path(const s2s_handle* h, int32_t* path, double* calibration_redo_rate);
+
 /* Counters of the predict kernel since the last call (every build; synchronises the device, then resets them).  The fast
  * softmax of the split-f16 decoder is data dependent -- a head whose later keys beat the first 64 keys' maximum by more than
  * the f16 range is redone on a safe path -- and the chip's clock under this kernel depends on the operands, so a throughput
@@ -265,7 +280,7 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
  *   [3] shader-clock cycles (s_memtime) and [4] 100 MHz ticks (s_memrealtime) of one thread per workgroup over the whole
  *       kernel, summed over [5] workgroups: [3] / [4] / 10 is the clock in GHz the SIMDs really ran at,
  *   [6] 16-key attention steps run without the P_lo product, [7] skipped entirely, [8] classified in all (0 unless the
- *       handle's tile classification is on: s2s_set_tile_classes), [9] reserved (0). */
+ *       heads ran on the exact attention path: s2s_set_attention_path), [9] reserved (0). */
 int s2s_stats_read(s2s_handle* h, uint64_t* out10);
 
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): per wave of a workgroup (8 rows) 48 per-phase shader-cycle sums

@@ -25,7 +25,7 @@ class S2SDebug(C.Structure):
 
 
 EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
-           "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_stats_read", "s2s_diag_read",
+           "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_stats_read", "s2s_set_attention_path", "s2s_get_attention_path", "s2s_diag_read",
            "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_fasta_count",
            "s2s_fasta_clean")
 
@@ -66,6 +66,10 @@ def lib():
     L.s2s_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
     L.s2s_stats_read.restype = i32
     L.s2s_stats_read.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.s2s_set_attention_path.restype = i32
+    L.s2s_set_attention_path.argtypes = [vp, i32]
+    L.s2s_get_attention_path.restype = i32
+    L.s2s_get_attention_path.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
     L.s2s_diag_read.restype = i32
     L.s2s_diag_read.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.s2s_blow5_pack_bound.restype = i64

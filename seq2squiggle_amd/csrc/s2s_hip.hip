@@ -381,7 +381,7 @@ __device__ __forceinline__ void dec_override(const float* __restrict__ dec_in, c
 // next_slot (MODE 1 only): the NEXT chunk's hand-off slot, copied into the LDS words behind the block's own image by the last
 // layer's FFN weight staging step (one more load per lane before its barrier, one more LDS store after it), so that the gather
 // that follows this chunk reads LDS instead of paying two dependent L2 round trips.
-template <int MODE>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h), 3: the same block with single f16 products
+template <int MODE, bool EXACT = false>   // 0: f32-input MFMA block, 1: split-f16 block (s2s_device_h.h), 3: the same block with single f16 products
 __device__ __forceinline__ void dec_blocks(const ModelDev& M, const float* __restrict__ W, f32x4 (&X)[DEC_NQ][4],
                                            char* __restrict__ lds_raw, const int wave, const int lane, const float one,
                                            unsigned long long* diag, const float* __restrict__ next_slot = nullptr) {
@@ -389,9 +389,9 @@ __device__ __forceinline__ void dec_blocks(const ModelDev& M, const float* __res
 #pragma unroll 1
     for (int l = 0; l < M.dec_layers; ++l) {
         float* const slot_lds = reinterpret_cast<float*>(lds_raw + DEC_LDS_H), *const sv_lds = slot_lds + S2S_SLOT_FLOATS;
-        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
+        if (MODE == 1) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, true, EXACT>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
                                                                           l == M.dec_layers - 1 ? next_slot : nullptr, slot_lds, sv_lds);
-        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
+        else if (MODE == 3) fft_block_h<DEC_NQ, DEC_WAVES, DEC_NKT, S2S_T_DEC, false, EXACT>(W, M.dec[l], X, lds_raw, qt0, wave, lane, one, diag,
                                                                                       nullptr, slot_lds, sv_lds);
         else           fft_block<DEC_NQ, DEC_NKT, S2S_T_DEC>(W, M.dec[l], X, reinterpret_cast<float*>(lds_raw), qt0, lane, diag);
     }
@@ -468,7 +468,9 @@ template <int MODE> struct Fused {
 // TEST = false is the production instance: no injected variates and no stage outputs, whose address arithmetic would otherwise
 // sit (and spill) in the hot loop; the parity tests that inject or ask for stage outputs run the TEST = true instance of the
 // same code.
-template <int MODE, bool TEST>
+// EXACT: the decoder attention's exact path (s2s_device_h.h: softmax_pv32_exact) instead of "fast path, redone on overflow" -- a
+// kernel instance of its own, so that neither path's registers and schedule depend on the other (split-f16 modes only).
+template <int MODE, bool TEST, bool EXACT = false>
 __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
     const ModelDev M, const float* __restrict__ W, const uint8_t* __restrict__ bases,
     const long long* __restrict__ chunk_start, const uint8_t* __restrict__ n_valid, int n_chunks, long long first_chunk,
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
             // (after the group's last chunk everything "next" is that chunk again, computed and thrown away: no branches here,
             // the register allocator spills values that live from one conditional block to another)
             const float* next = slot0 + (j + 1 < n_here ? j + 1 : j) * S2S_SLOT_FLOATS;
-            dec_blocks<MODE>(M, W, X, lds_raw, wave, lane, one, dbg.diag, F::PF ? next : nullptr);
+            dec_blocks<MODE, EXACT>(M, W, X, lds_raw, wave, lane, one, dbg.diag, F::PF ? next : nullptr);
             DIAG_STAMP(15);   // (time inside the blocks is accounted by their own stamps)
             // (an opaque copy of the lane id: the per-lane addresses below are recomputed per chunk, a handful of VALU
             // instructions, instead of being hoisted out of the loop and spilled across the blocks -- a scratch reload here
@@ -843,6 +845,9 @@ struct s2s_handle {
     unsigned long long* d_diag = nullptr;   // S2S_DIAG builds: [8 waves][48] per-phase wave-cycle sums (S2S_TILEHIST: the tile histogram)
     unsigned long long* d_stats = nullptr;  // S2S_STAT_* counters of the predict kernel (inside the slab; s2s_stats_read)
     long long stat_chunks = 0;              // chunks launched since the last s2s_stats_read
+    int attn_exact = 0;                     // decoder attention path of the split-f16 modes (s2s_set_attention_path)
+    long long stat_exact_chunks = 0;        // ... chunks launched on the exact path since the last s2s_stats_read
+    double calib_redo_rate = -1.0;          // share of the calibration launch's softmax runs that overflowed the fast path (-1: not calibrated)
     std::vector<EventPair> events;
     std::string err;
 };
@@ -1114,6 +1119,39 @@ size_t s2s_blob_floats(const s2s_config* c) {
            (size_t)(c->encoder_layers + c->decoder_layers) * layer_floats() + 3 * mlp_floats() + (size_t)250 * 64 + 64 + 1;
 }
 
+static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, const int64_t* chunk_start, const uint8_t* n_valid, int64_t first_global_chunk,
+                        int32_t B, const s2s_params* params, const float* inject_g, const float* inject_zdw,
+                        const float* inject_z01, float* out_signal, int32_t* out_dur, const s2s_debug* dbg);
+
+// Which softmax path the split-f16 decoder tries first is a property of the WEIGHTS: one launch of 512 pseudo-random chunks with the
+// default samplers on the fast path counts the heads it had to redo (the production counters); above a quarter the handle starts
+// every head on the exact path (s2s_device_h.h: softmax_pv32_exact).  A fixed input, so the same weights always get the same
+// answer, on any device.  The export scratch inside the slab holds the launch's buffers.
+static int calibrate_attention(s2s_handle* h) {
+    if (h->cfg.compute_mode == S2S_MODE_F32) return S2S_OK;
+    const int B = 512, nb = S2S_T_ENC + h->cfg.seq_kmer - 1;
+    std::vector<uint8_t> host((size_t)B * nb + B);
+    uint32_t x = 0x9E3779B9u;
+    for (size_t i = 0; i < (size_t)B * nb; ++i) { x = x * 1664525u + 1013904223u; host[i] = "ACGT"[x >> 30]; }
+    for (int i = 0; i < B; ++i) host[(size_t)B * nb + i] = S2S_T_ENC;
+    char* base = reinterpret_cast<char*>(h->ws_offs);               // (5 * 32768 + 1) * 8 bytes
+    float* sig = reinterpret_cast<float*>(base);
+    int32_t* dur = reinterpret_cast<int32_t*>(base + (size_t)B * S2S_T_DEC * 4);
+    uint8_t* d_bases = reinterpret_cast<uint8_t*>(base + (size_t)B * S2S_T_DEC * 4 + (size_t)B * 16 * 4);
+    static_assert((size_t)512 * S2S_T_DEC * 4 + 512 * 16 * 4 + 512 * 32 + 512 <= (size_t)(5 * 32768 + 1) * 8, "calibration buffers fit the export scratch");
+    HIP_TRY(h, hipMemcpy(d_bases, host.data(), host.size(), hipMemcpyHostToDevice));
+    const s2s_params P = {12.5f, 0.0f, 2.0f, 0.0f, 3.0f, 1, 1, 0};
+    h->attn_exact = 0;
+    const int rc = predict_impl(h, nullptr, d_bases, nullptr, d_bases + (size_t)B * nb, 0, B, &P, nullptr, nullptr, nullptr, sig, dur, nullptr);
+    if (rc != S2S_OK) return rc;
+    uint64_t st[10];
+    const int rs = s2s_stats_read(h, st);
+    if (rs != S2S_OK) return rs;
+    h->calib_redo_rate = st[1] ? (double)st[2] / (double)st[1] : 0.0;
+    h->attn_exact = h->calib_redo_rate > 0.25 ? 1 : 0;   // (measured break-even of "fast + redo" against the exact path: ~0.28, profiles/r04/attention_paths.txt)
+    return S2S_OK;
+}
+
 int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int device, s2s_handle** out) {
     if (!out) return fail(nullptr, S2S_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -1220,7 +1258,9 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     const struct { const void* fn; int bytes; } dyn_lds[] = {
         {reinterpret_cast<const void*>(s2s_fused_kernel<0, false>), Fused<0>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<1, false>), Fused<1>::LDS},
         {reinterpret_cast<const void*>(s2s_fused_kernel<3, false>), Fused<3>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<0, true>), Fused<0>::LDS},
-        {reinterpret_cast<const void*>(s2s_fused_kernel<1, true>), Fused<1>::LDS},  {reinterpret_cast<const void*>(s2s_fused_kernel<3, true>), Fused<3>::LDS}};
+        {reinterpret_cast<const void*>(s2s_fused_kernel<1, true>), Fused<1>::LDS},  {reinterpret_cast<const void*>(s2s_fused_kernel<3, true>), Fused<3>::LDS},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<1, false, true>), Fused<1>::LDS}, {reinterpret_cast<const void*>(s2s_fused_kernel<3, false, true>), Fused<3>::LDS},
+        {reinterpret_cast<const void*>(s2s_fused_kernel<1, true, true>), Fused<1>::LDS},  {reinterpret_cast<const void*>(s2s_fused_kernel<3, true, true>), Fused<3>::LDS}};
     for (const auto& k : dyn_lds)
         if ((e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes)) != hipSuccess)
             return bail(e, "hipFuncSetAttribute(dynamic LDS)");
@@ -1228,7 +1268,28 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipMalloc(&h->d_diag, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
     if ((e = hipMemset(h->d_diag, 0, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
 #endif
+    if (const char* env = getenv("S2S_ATTENTION_PATH")) {          // "fast" / "exact": no calibration launch
+        h->attn_exact = (env[0] == 'e' || env[0] == '1') ? 1 : 0;
+    } else if (calibrate_attention(h) != S2S_OK) {
+        g_create_error = "attention-path calibration launch: " + h->err;
+        s2s_destroy(h);
+        return S2S_ERR_HIP;
+    }
     *out = h;
+    return S2S_OK;
+}
+
+int s2s_set_attention_path(s2s_handle* h, int32_t path) {
+    if (!h) return S2S_ERR_ARG;
+    if (path != 0 && path != 1) return fail(h, S2S_ERR_ARG, "attention path must be 0 (fast path first) or 1 (exact path)");
+    h->attn_exact = path;
+    return S2S_OK;
+}
+
+int s2s_get_attention_path(const s2s_handle* h, int32_t* path, double* calibration_redo_rate) {
+    if (!h) return S2S_ERR_ARG;
+    if (path) *path = h->attn_exact;
+    if (calibration_redo_rate) *calibration_redo_rate = h->calib_redo_rate;
     return S2S_OK;
 }
 
@@ -1289,8 +1350,12 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
             HIP_TRY(h, hipEventRecord(ev.a, stream));
         }
         const bool test = dbg || inject_g || inject_zdw || inject_z01;
-        auto fused = test ? (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, true> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, true> : s2s_fused_kernel<0, true>)
-                          : (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, false> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, false> : s2s_fused_kernel<0, false>);
+        const bool exact = h->attn_exact && mode != S2S_MODE_F32;
+        auto fused = exact ? (test ? (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, true, true> : s2s_fused_kernel<1, true, true>)
+                                   : (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, false, true> : s2s_fused_kernel<1, false, true>))
+                   : test  ? (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, true> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, true> : s2s_fused_kernel<0, true>)
+                           : (mode == S2S_MODE_F16 ? s2s_fused_kernel<3, false> : mode == S2S_MODE_F16X3 ? s2s_fused_kernel<1, false> : s2s_fused_kernel<0, false>);
+        if (exact) h->stat_exact_chunks += n;
         hipLaunchKernelGGL(fused, grid, block, mode == S2S_MODE_F16 ? Fused<3>::LDS : mode == S2S_MODE_F16X3 ? Fused<1>::LDS : Fused<0>::LDS, stream, h->model, h->d_arena, tb, tcs,
                            n_valid + s, n, fc, P, tg, tzdw, tz01, h->handoff, out_dur + s * 16, tsig, D, (long long)s);
         if (h->profiling) {
@@ -1441,8 +1506,9 @@ int s2s_stats_read(s2s_handle* h, uint64_t* out10) {
     out10[1] = (uint64_t)h->stat_chunks * DEC_WAVES * S2S_HEADS * (uint64_t)h->cfg.decoder_layers;
     out10[2] = raw[S2S_STAT_REDO];
     out10[3] = raw[S2S_STAT_CYCLES]; out10[4] = raw[S2S_STAT_TICKS]; out10[5] = raw[S2S_STAT_WGS];
-    out10[6] = raw[S2S_STAT_TILES_HI]; out10[7] = raw[S2S_STAT_TILES_SKIP]; out10[8] = raw[S2S_STAT_TILES]; out10[9] = 0;
-    h->stat_chunks = 0;
+    out10[6] = raw[S2S_STAT_TILES_HI]; out10[7] = raw[S2S_STAT_TILES_SKIP];
+    out10[8] = (uint64_t)h->stat_exact_chunks * DEC_WAVES * S2S_HEADS * (uint64_t)h->cfg.decoder_layers * 16; out10[9] = 0;
+    h->stat_chunks = 0; h->stat_exact_chunks = 0;
     return S2S_OK;
 }
 

@@ -254,6 +254,26 @@ class Engine:
         self._check(_lib.lib().s2s_get_kernel_ms(self._h, C.byref(ms), C.byref(nl), C.byref(nc)), "s2s_get_kernel_ms")
         return ms.value, nl.value, nc.value
 
+    @property
+    def attention_path(self) -> str:
+        """"fast" (fast softmax path first, exact path on overflow) or "exact": chosen per checkpoint by s2s_create's calibration
+        launch, or set here (s2s_set_attention_path)."""
+        p, r = C.c_int32(), C.c_double()
+        self._check(_lib.lib().s2s_get_attention_path(self._h, C.byref(p), C.byref(r)), "s2s_get_attention_path")
+        return "exact" if p.value else "fast"
+
+    @attention_path.setter
+    def attention_path(self, path: str):
+        if path not in ("fast", "exact"):
+            raise ValueError("attention_path must be 'fast' or 'exact'")
+        self._check(_lib.lib().s2s_set_attention_path(self._h, int(path == "exact")), "s2s_set_attention_path")
+
+    @property
+    def calibration_redo_rate(self) -> float:
+        p, r = C.c_int32(), C.c_double()
+        self._check(_lib.lib().s2s_get_attention_path(self._h, C.byref(p), C.byref(r)), "s2s_get_attention_path")
+        return r.value
+
     def stats(self) -> dict:
         """Counters of the predict kernel since the last call (s2s_stats_read; synchronises the device): how THIS run behaved --
         the share of softmax runs redone on the safe path and the clock the SIMDs held are data dependent."""

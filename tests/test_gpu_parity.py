@@ -25,12 +25,20 @@ def P(**kw):
     return base
 
 
-@pytest.fixture(scope="module", params=[("k9", "f32"), ("k6", "f32"), ("k9", "f16x3"), ("k6", "f16x3")],
-                ids=lambda p: f"{p[0]}-{p[1]}")
+@pytest.fixture(scope="module", params=[("k9", "f32"), ("k6", "f32"), ("k9", "f16x3"), ("k6", "f16x3"),
+                                        ("k9", "f16x3", "exact"), ("k6", "f16x3", "exact")],
+                ids=lambda p: "-".join(p))
 def case(request):
-    tag, mode = request.param
+    """(checkpoint, arithmetic[, attention path]): the committed checkpoints calibrate to the fast softmax path; the "exact"
+    cases run every test of this file on the other one too (s2s_set_attention_path: running maximum, step classification)."""
+    tag, mode = request.param[:2]
     sd, cfg = load_ckpt(tag)
     eng = S.Engine(sd, cfg, mode=mode)
+    if mode != "f32":
+        assert eng.attention_path == "fast" and 0.0 <= eng.calibration_redo_rate < 0.1
+    if len(request.param) > 2:
+        eng.attention_path = request.param[2]
+        assert eng.attention_path == "exact"
     g = load_npz(f"stages_{tag}.npz")
     bases, nv = chunker.codes_to_bases(g["codes"])
     dev = eng.device
@@ -207,25 +215,38 @@ def test_peaked_attention_forces_the_rescale_fallback(mode, scale):
     ref = O.predict_chunks(sd, cfg, g["codes"], O.PredictParams(**p), inject_g=torch.from_numpy(g["g"]), stages=True)
     ref64 = O.predict_chunks(sd, cfg, g["codes"], O.PredictParams(**p), inject_g=torch.from_numpy(g["g"]), dtype=torch.float64)
     eng = S.Engine(sd, cfg, mode=mode)
-    eng.stats()
-    out = eng.predict_chunks(torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), S.PredictParams(**p),
-                             inject_g=torch.from_numpy(g["g"]).cuda())
-    y, r, t = out["signal"].cpu().numpy(), ref["signal"].numpy(), ref64["signal"].numpy()
-    st = eng.stats()                       # the production counters (s2s_stats_read) saw the rare branch
-    assert st["chunks"] == bases.shape[0] and st["softmax_runs"] == bases.shape[0] * 8 * 8 * 2
-    assert 1.0 < st["in_kernel_clock_ghz"] < 2.6 and st["workgroups"] == min(256, bases.shape[0])
-    if mode == "f16x3":
-        assert 0 < st["softmax_redone"] <= st["softmax_runs"], st
-    else:
-        assert st["softmax_redone"] == 0
-    assert eng.stats()["chunks"] == 0      # read-and-reset
-    assert np.isfinite(y).all()
-    same = ((y == 0) == (t == 0))
-    assert same.mean() > 0.999
-    # near-one-hot softmax amplifies rounding: judge both fp32 implementations by their distance to fp64
-    err_gpu = np.abs(y - t)[same].mean()
+    r, t = ref["signal"].numpy(), ref64["signal"].numpy()
     err_ref = np.abs(r - t)[(r == 0) == (t == 0)].mean()
-    assert err_gpu < max(5 * err_ref, 2e-4), (err_gpu, err_ref)
+    b_d, n_d, g_d = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), torch.from_numpy(g["g"]).cuda()
+    if mode == "f16x3":                    # s2s_create's calibration launch saw what these weights do to the fast path
+        assert eng.attention_path == "exact" and eng.calibration_redo_rate > 0.5
+    ys = {}
+    for path in (("fast", "exact") if mode == "f16x3" else ("fast",)):
+        if mode == "f16x3":
+            eng.attention_path = path
+        eng.stats()
+        out = eng.predict_chunks(b_d, n_d, S.PredictParams(**p), inject_g=g_d)
+        y = ys[path] = out["signal"].cpu().numpy()
+        st = eng.stats()                   # the production counters (s2s_stats_read)
+        assert st["chunks"] == bases.shape[0] and st["softmax_runs"] == bases.shape[0] * 8 * 8 * 2
+        assert 1.0 < st["in_kernel_clock_ghz"] < 2.6 and st["workgroups"] == min(256, bases.shape[0])
+        if mode == "f32":
+            assert st["softmax_redone"] == 0 and st["steps_classified"] == 0
+        elif path == "fast":               # ... saw the rare branch (the out-of-line online softmax)
+            assert 0.5 * st["softmax_runs"] < st["softmax_redone"] <= st["softmax_runs"], st
+            assert st["steps_classified"] == 0
+        else:                              # exact path at once: nothing to redo, every step classified, many of them skipped
+            assert st["softmax_redone"] == 0 and st["steps_classified"] == 16 * st["softmax_runs"]
+            assert st["steps_skipped"] > 0.05 * st["steps_classified"], st
+        assert eng.stats()["chunks"] == 0  # read-and-reset
+        assert np.isfinite(y).all()
+        same = ((y == 0) == (t == 0))
+        assert same.mean() > 0.999
+        # near-one-hot softmax amplifies rounding: judge both fp32 implementations by their distance to fp64
+        err_gpu = np.abs(y - t)[same].mean()
+        assert err_gpu < max(5 * err_ref, 2e-4), (path, err_gpu, err_ref)
+    if mode == "f16x3":                    # two roundings of the same (near-one-hot, rounding-amplifying) softmax
+        assert np.abs(ys["fast"] - ys["exact"]).mean() < max(5 * err_ref, 2e-4)
     eng.close()
 
 
@@ -243,7 +264,7 @@ def test_closer_to_fp64_truth_than_tolerance(case):
     assert np.abs(y - t)[same].mean() < MAE_TOL
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("mode", ["f32", "f16x3", "f16", "f16x3-exact", "f16-exact"])
 @pytest.mark.parametrize("tag", ["k9", "k6"])
 def test_production_instance_equals_test_instance(tag, mode):
     """`s2s_fused_kernel<MODE, false>` -- the production instance that bench.py, run_streaming and every un-instrumented
@@ -254,7 +275,9 @@ def test_production_instance_equals_test_instance(tag, mode):
     of length k; also through s2s_predict_packed, and in the Normal-dwell and constant-noise modes."""
     sd, cfg = load_ckpt(tag)
     k = cfg["seq_kmer"]
-    eng = S.Engine(sd, cfg, mode=mode)
+    eng = S.Engine(sd, cfg, mode=mode.split("-")[0])
+    if mode.endswith("-exact"):
+        eng.attention_path = "exact"
     dev = eng.device
     rng = np.random.default_rng(20263)
     lens = list(rng.integers(k, 900, size=170)) + [k, k + 15, k + 16, 5000]
