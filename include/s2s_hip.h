@@ -245,6 +245,17 @@ int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32
                            uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
                            int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i);
 
+/* The same replay for any of the reference's three read-length laws (utils.py:311-331; --distr): law 0 = expon (as above), 1 = gamma
+ * (scipy gamma.rvs(6.3693711, loc = 0.53834893) * r / 4.39), 2 = beta (beta.rvs(1.778, 7.892, loc = 316.758, scale = 34191.257) * r /
+ * 6615): numpy's legacy samplers -- Marsaglia-Tsang on the polar-method normal, whose cached second variate carries over between
+ * the two gammas of a beta -- mirrored draw for draw on a generator seeded per (read, retry).  s2s_length_law: one such length
+ * (test hook). */
+int64_t s2s_sampler_replay_law(uint32_t* mt_state, const int64_t* contig_ends, int32_t n_contigs,
+                               const int64_t* const* n_pos, const int64_t* n_pos_count, int64_t num_seqs, int64_t first_read_i, int64_t r,
+                               uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
+                               int64_t stop_after, int32_t law, int32_t* out_lengths, int64_t* out_next_read_i);
+int64_t s2s_length_law(int32_t law, uint32_t seed, double r, int64_t total_len);
+
 /* Plain FASTA text -> cleaned sequences on the host (no GPU): what utils.read_fasta (pysam.FastxFile, utils.py:290-308) and
  * process_genome (upper-case, non-ACGT -> N: utils.py:594-597) do line by line in the interpreter; every rank of a sharded
  * run parses the whole reference before its first kernel.  s2s_fasta_count: number of records ('>' first on a line), -2 when
@@ -253,6 +264,12 @@ int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32
  * delimits them; name_span [2*records]: begin / end of each record's name (first token of its header) inside data.
  * Returns the number of records, -1 when there are more than max_records. */
 int64_t s2s_fasta_count(const uint8_t* data, int64_t n);
+/* Four-line FASTQ records the same way (--read-input files; pysam.FastxFile reads either format): `out` receives the sequence
+ * lines as they stand minus their line ends (map_acgtn as above); -2 for anything the caller's line loop must judge itself (no '@'
+ * where a header should be, a missing '+' line, a truncated record, a lone carriage return inside a line); out == NULL with
+ * max_records == 0 only counts the records. */
+int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
+                        int64_t* name_span, int64_t max_records);
 int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
                         int64_t* name_span, int64_t max_records);
 

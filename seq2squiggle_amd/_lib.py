@@ -26,8 +26,8 @@ class S2SDebug(C.Structure):
 
 EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
            "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_stats_read", "s2s_set_attention_path", "s2s_get_attention_path", "s2s_diag_read",
-           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_fasta_count",
-           "s2s_fasta_clean")
+           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_sampler_replay_law", "s2s_length_law",
+           "s2s_fasta_count", "s2s_fasta_clean", "s2s_fastq_clean")
 
 
 def lib():
@@ -80,6 +80,12 @@ def lib():
     L.s2s_compress_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, i64, vp]
     L.s2s_sampler_replay.restype = i64
     L.s2s_sampler_replay.argtypes = [vp, vp, i32, vp, vp, i64, i64, i64, u64, i64, i32, i32, i32, i64, vp, vp]
+    L.s2s_sampler_replay_law.restype = i64
+    L.s2s_sampler_replay_law.argtypes = [vp, vp, i32, vp, vp, i64, i64, i64, u64, i64, i32, i32, i32, i64, i32, vp, vp]
+    L.s2s_length_law.restype = i64
+    L.s2s_length_law.argtypes = [i32, u32, C.c_double, i64]
+    L.s2s_fastq_clean.restype = i64
+    L.s2s_fastq_clean.argtypes = [vp, i64, i32, vp, vp, vp, i64]
     L.s2s_fasta_count.restype = i64
     L.s2s_fasta_count.argtypes = [vp, i64]
     L.s2s_fasta_clean.restype = i64

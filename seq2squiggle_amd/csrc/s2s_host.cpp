@@ -592,6 +592,85 @@ int64_t expon_length(uint32_t seed, double r, int64_t total_len) {
     return expon_from_words(w, r, total_len);
 }
 
+// ---- the other two length laws (reference utils.py:311-322): scipy's gamma.rvs / beta.rvs on a fresh np.random.RandomState(seed)
+// are numpy's LEGACY samplers (legacy-distributions.c): standard_gamma by Marsaglia-Tsang on legacy_gauss (the polar method, which
+// keeps its second variate for the next call -- also across the two gammas of a beta) and 53-bit doubles of MT19937.  They consume
+// a variable number of generator outputs, so the whole state is seeded (623 multiplies, ~1 us per (read, try)).
+struct NpLegacy {
+    uint32_t mt[624];
+    int pos = 624;
+    bool has_gauss = false;
+    double gauss = 0.0;
+    explicit NpLegacy(uint32_t seed) {
+        mt[0] = seed;
+        for (uint32_t i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i;
+    }
+    uint32_t next() {
+        if (pos >= 624) {
+            Mt19937 g{mt, 624};
+            (void)g.next();                                       // regenerates the block (and tempers word 0, which we redo below)
+            pos = 0;
+        }
+        return mt_temper(mt[pos++]);
+    }
+    double dbl() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    double normal() {
+        if (has_gauss) { has_gauss = false; const double t = gauss; gauss = 0.0; return t; }
+        double f, x1, x2, r2;
+        do {
+            x1 = 2.0 * dbl() - 1.0;
+            x2 = 2.0 * dbl() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        f = std::sqrt(-2.0 * std::log(r2) / r2);
+        gauss = f * x1;
+        has_gauss = true;
+        return f * x2;
+    }
+    double std_gamma(double shape) {                              // shape > 1 (both laws)
+        const double b = shape - 1.0 / 3.0, c = 1.0 / std::sqrt(9.0 * b);
+        for (;;) {
+            double X, V;
+            do {
+                X = normal();
+                V = 1.0 + c * X;
+            } while (V <= 0.0);
+            V = V * V * V;
+            const double U = dbl();
+            if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return b * V;
+            if (std::log(U) < 0.5 * X * X + b * (1.0 - V + std::log(V))) return b * V;
+        }
+    }
+};
+
+// law 0: expon (above); 1: gamma.rvs(6.3693711, loc = 0.53834893) * r / 4.39; 2: beta.rvs(1.778, 7.892, loc = 316.758,
+// scale = 34191.257) * r / 6615 -- scipy returns vals * scale + loc; then int(), clipped to [1, total_len]
+int64_t law_length(int32_t law, uint32_t seed, double r, int64_t total_len) {
+    if (law == 0) return expon_length(seed, r, total_len);
+    NpLegacy g(seed);
+    double v, fitted;
+    if (law == 1) {
+        v = g.std_gamma(6.3693711);
+        v = v * 1.0 + 0.53834893;
+        fitted = 4.39;
+    } else {
+        const double ga = g.std_gamma(1.778), gb = g.std_gamma(7.892);
+        v = ga / (ga + gb);
+        v = v * 34191.257;
+        v = v + 316.758;
+        fitted = 6615.0;
+    }
+    v = v * r;
+    v = v / fitted;
+    int64_t n = (int64_t)v;
+    if (n < 1) n = 1;
+    if (n > total_len) n = total_len;
+    return n;
+}
+
 // The seeding recurrence is a serial chain of 398 multiplies per seed (0.5 us): eight seeds at a time fill the lanes of one AVX2
 // register (the first tries of eight consecutive reads; retries stay scalar).  Same integer arithmetic, lane by lane.
 #define S2S_MT_WORDS8_BODY                                                                          \
@@ -613,11 +692,12 @@ void mt_words8(const uint32_t* seeds, MtWords* out) {
 
 }  // namespace
 
-extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32_t n_contigs,
-                                      const int64_t* const* n_pos, const int64_t* n_pos_count, int64_t num_seqs, int64_t first_read_i, int64_t r,
-                                      uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
-                                      int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i) {
-    if (!mt_state || !contig_ends || n_contigs < 1 || num_seqs < 0 || first_read_i < 0 || r <= 0 || max_retries < 1 || !out_next_read_i)
+extern "C" int64_t s2s_sampler_replay_law(uint32_t* mt_state, const int64_t* contig_ends, int32_t n_contigs,
+                                          const int64_t* const* n_pos, const int64_t* n_pos_count, int64_t num_seqs, int64_t first_read_i, int64_t r,
+                                          uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
+                                          int64_t stop_after, int32_t law, int32_t* out_lengths, int64_t* out_next_read_i) {
+    if (!mt_state || !contig_ends || n_contigs < 1 || num_seqs < 0 || first_read_i < 0 || r <= 0 || max_retries < 1 || !out_next_read_i ||
+        law < 0 || law > 2)
         return S2S_ERR_ARG;
     const int64_t genome = contig_ends[n_contigs - 1];
     if (genome < 1 || genome >= (1ll << 31) || mt_state[624] > 624) return S2S_ERR_ARG;
@@ -626,7 +706,7 @@ extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_
     int64_t accepted = 0, read_i = first_read_i;
     int64_t first_try[8], first_base = -1;                    // lengths of the first tries of reads first_base .. first_base + 7
     for (; read_i < num_seqs && (stop_after < 0 || accepted < stop_after); ++read_i) {
-        if (first_base < 0 || read_i >= first_base + 8) {
+        if (law == 0 && (first_base < 0 || read_i >= first_base + 8)) {
             uint32_t seeds[8];
             MtWords w[8];
             for (int l = 0; l < 8; ++l) seeds[l] = (uint32_t)(seed + (uint64_t)(read_i + l) * (uint64_t)(max_retries + 1));
@@ -639,9 +719,9 @@ extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_
             const int64_t* ce = std::upper_bound(contig_ends, contig_ends + n_contigs, pos);   // bisect_right
             const int where = (int)(ce - contig_ends);
             const int64_t start = where ? contig_ends[where - 1] : 0, offset = pos - start, clen = contig_ends[where] - start;
-            const int64_t length = retry == 0 ? first_try[read_i - first_base]
-                                              : expon_length((uint32_t)(seed + (uint64_t)read_i * (uint64_t)(max_retries + 1) + (uint64_t)retry),
-                                                             (double)r, total_len);
+            const int64_t length = (retry == 0 && law == 0) ? first_try[read_i - first_base]
+                                              : law_length(law, (uint32_t)(seed + (uint64_t)read_i * (uint64_t)(max_retries + 1) + (uint64_t)retry),
+                                                           (double)r, total_len);
             const int64_t got = std::min(length, clen - offset);                     // genome[offset : offset + length]
             if (is_dna) (void)g.below(2);                                           // random.choice("+-")
             if (is_dna && got != length) continue;                                  // read_check: end-of-contig rejection
@@ -661,6 +741,20 @@ extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_
     mt_state[624] = g.idx;
     *out_next_read_i = read_i;
     return accepted;
+}
+
+extern "C" int64_t s2s_sampler_replay(uint32_t* mt_state, const int64_t* contig_ends, int32_t n_contigs,
+                                      const int64_t* const* n_pos, const int64_t* n_pos_count, int64_t num_seqs, int64_t first_read_i, int64_t r,
+                                      uint64_t seed, int64_t total_len, int32_t is_dna, int32_t min_read_len, int32_t max_retries,
+                                      int64_t stop_after, int32_t* out_lengths, int64_t* out_next_read_i) {
+    return s2s_sampler_replay_law(mt_state, contig_ends, n_contigs, n_pos, n_pos_count, num_seqs, first_read_i, r, seed, total_len, is_dna,
+                                  min_read_len, max_retries, stop_after, 0, out_lengths, out_next_read_i);
+}
+
+// One read length of law 0 / 1 / 2 (expon / gamma / beta) for a scipy seed: the test hook of the three laws.
+extern "C" int64_t s2s_length_law(int32_t law, uint32_t seed, double r, int64_t total_len) {
+    if (law < 0 || law > 2 || !(r > 0) || total_len < 1) return S2S_ERR_ARG;
+    return law_length(law, seed, r, total_len);
 }
 
 // ---- FASTA text -> cleaned sequences (replaces the line loop of utils.read_fasta + process_genome, reference utils.py:290-308,
@@ -734,5 +828,63 @@ extern "C" int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_a
         i = next;
     }
     seq_offs[recs] = o;
+    return recs;
+}
+
+// FASTQ text (four-line records, as the line loop of utils.read_fasta takes them: blank lines are skipped in front of a header only,
+// the sequence line is kept as it stands minus its line end, the third line must start with '+', the fourth is skipped) -> the
+// sequences back to back in `out` (>= n bytes; map_acgtn as in s2s_fasta_clean), seq_offs [records + 1], name_span [2 * records]
+// (the header's first token inside data).  Returns the number of records; -1 when there are more than max_records; -2 for
+// anything the line loop must judge itself (no '@' where a header should be, a missing '+', a truncated last record, a lone
+// carriage return inside a line -- a line break for Python's universal newlines).  max_records = 0 with out == NULL only counts.
+extern "C" int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
+                                   int64_t* name_span, int64_t max_records) {
+    if (!data || n < 0 || max_records < 0) return S2S_ERR_ARG;
+    const bool count_only = out == nullptr;
+    if (!count_only && (!seq_offs || !name_span)) return S2S_ERR_ARG;
+    uint8_t tab[256];
+    for (int c = 0; c < 256; ++c) {
+        uint8_t u = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : (uint8_t)c;
+        tab[c] = map_acgtn ? ((u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : (uint8_t)'N') : (uint8_t)c;
+    }
+    int64_t i = 0, recs = 0, o = 0;
+    bool bad = false;
+    auto line = [&](int64_t& b, int64_t& e) {                // next line [b, e) without its line end; false at the end of the data
+        if (i >= n) return false;
+        const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(data + i, '\n', (size_t)(n - i)));
+        e = nl ? nl - data : n;
+        b = i;
+        i = e + 1;
+        while (e > b && data[e - 1] == '\r') --e;
+        if (e > b && std::memchr(data + b, '\r', (size_t)(e - b))) bad = true;
+        return true;
+    };
+    int64_t b, e;
+    while (line(b, e)) {
+        if (bad) return -2;
+        if (e == b) continue;
+        if (data[b] != '@') return -2;
+        int64_t s = b + 1;
+        while (s < e && fa_blank(data[s])) ++s;
+        int64_t t = s;
+        while (t < e && !fa_blank(data[t])) ++t;
+        int64_t sb, se, pb, pe, qb, qe;
+        if (!line(sb, se) || !line(pb, pe) || !line(qb, qe) || bad) return -2;
+        if (pe == pb || data[pb] != '+') return -2;
+        if (!count_only) {
+            if (recs == max_records) return -1;
+            seq_offs[recs] = o;
+            name_span[2 * recs] = s;
+            name_span[2 * recs + 1] = t;
+            if (map_acgtn) {
+                for (int64_t k = sb; k < se; ++k) out[o + (k - sb)] = tab[data[k]];
+            } else {
+                std::memcpy(out + o, data + sb, (size_t)(se - sb));
+            }
+            o += se - sb;
+        }
+        ++recs;
+    }
+    if (!count_only) seq_offs[recs] = o;
     return recs;
 }

@@ -76,7 +76,8 @@ def _read_fasta_native(path, map_acgtn: bool = False, limit: int = 4 << 30):
     """Plain (not gzipped) FASTA files through the library's host-side parser (s2s_fasta_clean): the same (sequence, name)
     pairs as the line loop of read_fasta -- with map_acgtn also process_genome's upper-casing and non-ACGT -> N -- without the
     interpreter touching a line (a 100 Mb reference: 0.1 s instead of 0.7 s, which every rank of a sharded run pays before its
-    first kernel).  None: not applicable (FASTQ, gzip, files over 4 GB, library not built), the caller falls back to the line loop."""
+    first kernel); four-line FASTQ files through s2s_fastq_clean.  None: not applicable (gzip, files over 4 GB, odd FASTQ, library
+    not built), the caller falls back to the line loop."""
     path = str(path)
     try:
         if path.endswith(".gz"):
@@ -92,13 +93,17 @@ def _read_fasta_native(path, map_acgtn: bool = False, limit: int = 4 << 30):
     except Exception:
         return None
     n_rec = int(L.s2s_fasta_count(data.ctypes.data, size))
+    clean = L.s2s_fasta_clean
+    if n_rec == -2:                          # not FASTA: four-line FASTQ records, or something the line loop has to judge
+        n_rec = int(L.s2s_fastq_clean(data.ctypes.data, size, 0, None, None, None, 0))
+        clean = L.s2s_fastq_clean
     if n_rec < 0:
-        return None                          # FASTQ (or something else): the line loop decides
+        return None
     out = np.empty(size, np.uint8)
     seq_offs = np.zeros(n_rec + 1, np.int64)
     names = np.zeros(2 * n_rec + 2, np.int64)
-    got = int(L.s2s_fasta_clean(data.ctypes.data, size, 1 if map_acgtn else 0, out.ctypes.data, seq_offs.ctypes.data,
-                                names.ctypes.data, n_rec))
+    got = int(clean(data.ctypes.data, size, 1 if map_acgtn else 0, out.ctypes.data, seq_offs.ctypes.data,
+                    names.ctypes.data, n_rec))
     if got != n_rec:
         return None
     recs = []
@@ -155,6 +160,9 @@ _LENGTH_LAWS = {
     "beta": (st.beta, dict(a=1.778, b=7.892, loc=316.758, scale=34191.257), 6615.0),
     "gamma": (st.gamma, dict(a=6.3693711, loc=0.53834893), 4.39),
 }
+
+
+_NATIVE_LAWS = {"expon": 0, "gamma": 1, "beta": 2}     # s2s_sampler_replay_law's `law`: numpy's legacy samplers mirrored draw for draw
 
 
 def draw_length(distr: str, mean, seed, total_len):
@@ -252,11 +260,11 @@ def replay_sampler(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr
     """The draws of sampling_iter() for reads first_read_i.. without building a read, in native code (s2s_sampler_replay in
     libs2s_hip.so, host only): advances the global `random` generator exactly as sampling_iter would and returns
     (lengths of the accepted reads | None, index of the next read to attempt) -- or None when the native path does not
-    apply (another length law, a seed outside the scipy fast range, a genome of 2 Gb or more, library not loadable): the
+    apply (a non-integer -r, a seed outside the scipy fast range, a genome of 2 Gb or more, library not loadable): the
     caller then replays in Python.  stop_after: stop once that many reads have been accepted."""
     import ctypes as C
     genome_total = sum(genome_lens)
-    if distr != "expon" or r <= 0 or not (0 <= seed and seed + num_seqs * (max_retries + 1) < 2 ** 32) or genome_total >= 2 ** 31:
+    if distr not in _NATIVE_LAWS or r <= 0 or int(r) != r or not (0 <= seed and seed + num_seqs * (max_retries + 1) < 2 ** 32) or genome_total >= 2 ** 31:
         return None
     try:
         from ._lib import lib
@@ -278,10 +286,10 @@ def replay_sampler(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr
     n_left = max(num_seqs - first_read_i, 0)
     out = np.empty(n_left if stop_after < 0 else min(n_left, stop_after), np.int32) if want_lengths else None
     nxt = C.c_int64(0)
-    got = L.s2s_sampler_replay(state.ctypes.data, ends.ctypes.data, len(ends), C.cast(ptrs, C.c_void_p), counts.ctypes.data, int(num_seqs),
-                               int(first_read_i), int(r), int(seed), int(total_len), int(profile.startswith("dna")),
-                               int(min_read_len), int(max_retries), int(stop_after), None if out is None else out.ctypes.data,
-                               C.byref(nxt))
+    got = L.s2s_sampler_replay_law(state.ctypes.data, ends.ctypes.data, len(ends), C.cast(ptrs, C.c_void_p), counts.ctypes.data, int(num_seqs),
+                                   int(first_read_i), int(r), int(seed), int(total_len), int(profile.startswith("dna")),
+                                   int(min_read_len), int(max_retries), int(stop_after), _NATIVE_LAWS[distr],
+                                   None if out is None else out.ctypes.data, C.byref(nxt))
     if got < 0:
         return None
     random.setstate((3, tuple(int(x) for x in state), gauss))

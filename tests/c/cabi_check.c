@@ -18,8 +18,8 @@ int main(int argc, char** argv) {
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
     const char* names[] = {"s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
                            "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_stats_read", "s2s_set_attention_path", "s2s_get_attention_path", "s2s_diag_read",
-                           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_fasta_count",
-                           "s2s_fasta_clean"};
+                           "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_sampler_replay_law", "s2s_length_law",
+                           "s2s_fasta_count", "s2s_fasta_clean", "s2s_fastq_clean"};
     for (unsigned i = 0; i < sizeof names / sizeof *names; ++i)
         if (!dlsym(lib, names[i])) { fprintf(stderr, "missing symbol %s\n", names[i]); return 4; }
     blob_floats_fn blob_floats = (blob_floats_fn)dlsym(lib, "s2s_blob_floats");

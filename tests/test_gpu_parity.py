@@ -452,28 +452,30 @@ def test_full_size_properties():
     eng.close()
 
 
-def test_maximum_batch_in_one_call():
-    """BASELINE.json configs[2] per-GPU share (12,500 reads x 5 kb ~ 3.9 M chunks, 4 GB of fp32 signal) in ONE call: four
-    launches of <= 2^20 chunks, 64-bit row offsets; spot windows across the batch must equal small separate calls (counter-based RNG),
-    and the export of the whole batch must add up."""
-    sd, cfg = load_ckpt("k9")
+@pytest.mark.parametrize("tag,per_read,noise_std", [("k9", 312, 2.0), ("k6", 500, 1.5)])
+def test_maximum_batch_in_one_call(tag, per_read, noise_std):
+    """BASELINE.json configs[2] / configs[3] per-GPU share (12,500 reads x 5 kb ~ 3.9 M chunks, 4 GB of fp32 signal; k = 6 with
+    noise_std 1.5: 12,500 x 8 kb = 6.25 M chunks, 6.25 GB) in ONE call: four / six launches of <= 2^20 chunks, 64-bit row offsets,
+    RNG counters beyond 2^32; spot windows across the batch must equal small separate calls (counter-based RNG), and the export
+    of the whole batch must add up."""
+    sd, cfg = load_ckpt(tag)
     eng = S.Engine(sd, cfg, mode="f16x3")
     rng = np.random.default_rng(7)
-    B = 12500 * 312
-    nb = 24
+    B = 12500 * per_read
+    nb = 16 + cfg["seq_kmer"] - 1
     bases = torch.from_numpy(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (4096, nb))]).cuda()
     bases = bases.repeat(B // 4096 + 1, 1)[:B].contiguous()             # 4096 distinct chunks tiled (the RNG still differs per chunk)
     nv = torch.full((B,), 16, dtype=torch.uint8, device="cuda")
-    pp = S.PredictParams(seed=3)
+    pp = S.PredictParams(seed=3, noise_std=noise_std)
     full = eng.predict_chunks(bases, nv, pp, first_global_chunk=5_000_000_000)      # counters beyond 2^32
     sig, dur = full["signal"], full["dur"]
     assert sig.shape == (B, 250) and bool(torch.isfinite(sig[::997]).all()) and int(dur.min()) >= 3
-    for lo in (0, 32768 * 57 - 5, B - 4099):
+    for lo in (0, 32768 * 57 - 5, (1 << 20) - 2050, B - 4099):         # (the third window straddles the first launch boundary)
         part = eng.predict_chunks(bases[lo:lo + 4099].contiguous(), nv[lo:lo + 4099].contiguous(), pp,
                                   first_global_chunk=5_000_000_000 + lo)
         assert torch.equal(part["signal"], sig[lo:lo + 4099]) and torch.equal(part["dur"], dur[lo:lo + 4099])
     assert not torch.equal(sig[:4096], sig[4096:8192])                  # same bases, different chunk index: different draws
-    first = torch.arange(0, B + 1, 312, dtype=torch.int32, device="cuda")
+    first = torch.arange(0, B + 1, per_read, dtype=torch.int32, device="cuda")
     ex = eng.export_reads(sig, first, 2048.0, 281.345551, -127.5655735, want_pa=False, want_dac=True)
     offs = ex["offsets"].cpu().numpy()
     assert offs[-1] == int((sig != 0).sum()) > 2 ** 29 and (np.diff(offs) > 0).all()

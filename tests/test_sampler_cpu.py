@@ -130,10 +130,12 @@ def test_sharded_sampling_equals_slices_of_the_full_read_set(world, block, monke
     assert got == full and any("N" in s for s in seqs)
 
 
+@pytest.mark.parametrize("distr", ["expon", "gamma", "beta"])
 @pytest.mark.parametrize("profile,r,n_frac,min_len", [("dna-r10-prom", 3000, 0.04, 30), ("rna-004-prom", 2500, 0.02, 30),
                                                       ("dna-r9-min", 300000, 0.0, 30), ("dna-r10-min", 400, 0.12, 300)])
-def test_native_replay_equals_the_interpreter_draw_for_draw(profile, r, n_frac, min_len):
-    """s2s_sampler_replay (the rank skip-ahead of sharded runs) against sampling_iter: same accepted-read lengths, same
+def test_native_replay_equals_the_interpreter_draw_for_draw(profile, r, n_frac, min_len, distr):
+    """s2s_sampler_replay_law (the rank skip-ahead of sharded runs) against sampling_iter, for each of the reference's three
+    read-length laws (--distr expon | gamma | beta, utils.py:311-331: scipy on a generator seeded per (read, retry)): same accepted-read lengths, same
     index of the next read, and the SAME `random` generator state afterwards -- with N runs (extra draws), end-of-contig
     rejections, N-rich rejections (> 10 % N), reads whose 20 retries all fail (-r 300000 on 7-30 kb contigs) and an RNA
     profile (no strand draw, short reads allowed); also stopped part-way (stop_after) and resumed."""
@@ -148,27 +150,41 @@ def test_native_replay_equals_the_interpreter_draw_for_draw(profile, r, n_frac, 
         contigs.append("".join(s))
     seqs, lens = zip(*[U.process_genome(s) for s in contigs])
     seqs, lens = list(seqs), list(lens)
-    total, seed, n = sum(lens), 77, 400
+    total, seed, n = sum(lens), 77, (400 if distr == "expon" else 150)
     random.seed(seed)
-    want = U.sampling(n, seqs, lens, r, seed, total, "expon", profile, min_len, materialise=(0, 0))
+    want = U.sampling(n, seqs, lens, r, seed, total, distr, profile, min_len, materialise=(0, 0))
     end_state = random.getstate()
     random.seed(seed)
-    got = U.replay_sampler(n, seqs, lens, r, seed, total, "expon", profile, min_len)
+    got = U.replay_sampler(n, seqs, lens, r, seed, total, distr, profile, min_len)
     assert got is not None, "native replay unavailable"
     assert got[0].tolist() == want and got[1] == n and random.getstate() == end_state
-    assert 0 < len(want) <= n and (r < 300000 or len(want) < n)                     # the 300 kb case loses reads to 20 failed retries
+    assert len(want) <= n and (r < 300000 or len(want) < n)                         # the 300 kb case loses reads to 20 failed retries
+    assert len(want) > 0 or (r == 300000 and distr != "expon")                      # (... all of them under the narrower laws)
     # stop part-way, then let the interpreter continue from there: the tail must be the same reads
     k = len(want) // 3
     random.seed(seed)
-    full = U.sampling(n, seqs, lens, r, seed, total, "expon", profile, min_len)
+    full = U.sampling(n, seqs, lens, r, seed, total, distr, profile, min_len)
     random.seed(seed)
-    part = U.replay_sampler(n, seqs, lens, r, seed, total, "expon", profile, min_len, stop_after=k)
+    part = U.replay_sampler(n, seqs, lens, r, seed, total, distr, profile, min_len, stop_after=k)
     assert part[0].tolist() == want[:k]
-    rest = list(U.sampling_iter(n, seqs, lens, r, seed, total, "expon", profile, min_len, first_read_i=part[1], n_accepted=k))
+    rest = list(U.sampling_iter(n, seqs, lens, r, seed, total, distr, profile, min_len, first_read_i=part[1], n_accepted=k))
     assert rest == full[k:] and random.getstate() == end_state
-    # cases the native path must decline (-> None): another length law, a seed beyond the scipy fast range
-    assert U.replay_sampler(n, seqs, lens, r, seed, total, "gamma", profile, min_len) is None
-    assert U.replay_sampler(n, seqs, lens, r, 2 ** 32 - 100, total, "expon", profile, min_len) is None
+    # cases the native path must decline (-> None): a seed beyond the scipy fast range, a fractional -r
+    assert U.replay_sampler(n, seqs, lens, r, 2 ** 32 - 100, total, distr, profile, min_len) is None
+    assert U.replay_sampler(n, seqs, lens, r + 0.5, seed, total, distr, profile, min_len) is None
+
+
+def test_native_length_laws_equal_scipy():
+    """s2s_length_law (numpy's legacy standard_gamma / beta on a per-seed MT19937, mirrored in the host library) against
+    utils.draw_length (scipy expon / gamma / beta .rvs with random_state = seed), seeds across the 32-bit range."""
+    from seq2squiggle_amd._lib import lib
+    L = lib()
+    rng = np.random.default_rng(5)
+    seeds = list(range(300)) + [2 ** 32 - 1, 2 ** 31] + [int(x) for x in rng.integers(0, 2 ** 32, 300)]
+    for law, name in enumerate(("expon", "gamma", "beta")):
+        for seed in seeds:
+            for r in (5000, 137):
+                assert L.s2s_length_law(law, seed, float(r), 48502) == int(U.draw_length(name, r, seed, 48502)), (name, seed, r)
 
 
 def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
@@ -215,13 +231,36 @@ def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
         p.write_text(text, newline="")
         native, loop = both(str(p))
         assert native == loop
-    # the native path is really taken for plain FASTA, and not for gzip / FASTQ
+    # four-line FASTQ through s2s_fastq_clean: same records as the line loop, odd files handed back to it (same exception or result)
+    fq = {
+        "fq_plain": "@q1 desc\nACGT\n+\nIIII\n@q2\nacgtn\n+q2\nIIIII\n", "fq_crlf": "@q1\r\nACGT\r\n+\r\nIIII\r\n", "fq_blank_between": "@a\nAC\n+\nII\n\n\n@b\nGT\n+\nII\n",
+        "fq_no_final_newline": "@a\nAC\n+\nII", "fq_empty_seq": "@a\n\n+\n\n@b\nAC\n+\nII\n", "fq_truncated": "@a\nAC\n+\n", "fq_no_plus": "@a\nAC\nII\nII\n",
+        "fq_bad_header": "@a\nAC\n+\nII\nxx\nAC\n+\nII\n", "fq_at_quality": "@a\nAC\n+\n@I\n@b\nGG\n+\nII\n", "fq_spaces": "@a  x\n AC GT \n+\nIIIIIII\n",
+        "fq_lone_cr": "@a\nAC\rGT\n+\nIIIII\n", "fq_noname": "@\nAC\n+\nII\n",
+    }
+    for name, text in fq.items():
+        p = tmp_path / f"{name}.fastq"
+        p.write_text(text, encoding="latin-1", newline="")
+        native, loop = both(str(p))
+        assert native == loop, (name, native, loop)
+    assert U._read_fasta_native(str(tmp_path / "fq_plain.fastq")) == [("ACGT", "q1"), ("acgtn", "q2")]
+    assert U._read_fasta_native(str(tmp_path / "fq_no_plus.fastq")) is None
+    for it in range(20):
+        text = ""
+        for i in range(int(rng.integers(1, 8))):
+            sq = "".join(rng.choice(list("ACGTNacgt"), int(rng.integers(0, 300))))
+            text += f"@r{i} d{it}\n{sq}\n+\n{'I' * len(sq)}\n".replace("\n", "\r\n" if it % 2 else "\n") + ("\n" if it % 3 == 0 else "")
+        p = tmp_path / "rand.fq"
+        p.write_text(text, newline="")
+        native, loop = both(str(p))
+        assert native == loop and native[0] != "raised"
+    # the native path is really taken for plain FASTA, and not for gzip
     assert U._read_fasta_native(os.path.join(GOLDEN, "example_test.fasta")) is not None
     gz = tmp_path / "x.fa.gz"
     with gzip.open(gz, "wt") as f:
         f.write(">a\nACGT\n")
     assert U._read_fasta_native(str(gz)) is None and list(U.read_fasta(str(gz))) == [("ACGT", "a")]
-    assert U._read_fasta_native(str(tmp_path / "fastq.fa")) is None
+    assert U._read_fasta_native(str(tmp_path / "fastq.fa")) == [("ACGT", "q1")]
     monkeypatch.setenv("S2S_FASTA_NATIVE_LIMIT", "10")                      # larger files stream through the line loop
     assert U._read_fasta_native(os.path.join(GOLDEN, "example_test.fasta")) is None
 
