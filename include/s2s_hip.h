@@ -259,7 +259,8 @@ int64_t s2s_length_law(int32_t law, uint32_t seed, double r, int64_t total_len);
 /* Plain FASTA text -> cleaned sequences on the host (no GPU): what utils.read_fasta (pysam.FastxFile, utils.py:290-308) and
  * process_genome (upper-case, non-ACGT -> N: utils.py:594-597) do line by line in the interpreter; every rank of a sharded
  * run parses the whole reference before its first kernel.  s2s_fasta_count: number of records ('>' first on a line), -2 when
- * the first non-blank line is no FASTA header (FASTQ, ...).  s2s_fasta_clean: out (>= n bytes) receives the sequences back to
+ * the first non-blank line starts with '@' (FASTQ: s2s_fastq_clean), -3 when a line holds a lone carriage return (a line break
+ * of its own for the reference's reader: the caller's line loop decides).  s2s_fasta_clean: out (>= n bytes) receives the sequences back to
  * back, line ends removed and lines stripped of blanks; map_acgtn = 1 applies process_genome's mapping; seq_offs [records+1]
  * delimits them; name_span [2*records]: begin / end of each record's name (first token of its header) inside data.
  * Returns the number of records, -1 when there are more than max_records. */

@@ -764,16 +764,19 @@ inline bool fa_blank(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c
 }  // namespace
 
 // Number of records ('>' in column 0, as pysam / the line loop of utils.read_fasta take it); -2 when the first non-empty line
-// starts with '@' (FASTQ: left to the caller's line loop).
+// starts with '@' (FASTQ: s2s_fastq_clean); -3 when a line holds a carriage return that is not part of its line end (a line
+// break of its own under Python's universal newlines: left to the caller's line loop; found by tools/fuzz_host.py).
 extern "C" int64_t s2s_fasta_count(const uint8_t* data, int64_t n) {
     if (!data || n < 0) return S2S_ERR_ARG;
     int64_t i = 0, recs = 0;
     bool first = true;
+    const bool has_cr = n > 0 && std::memchr(data, '\r', (size_t)n) != nullptr;      // (Unix files: one pass, no per-line check)
     while (i < n) {
         const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(data + i, '\n', (size_t)(n - i)));
         int64_t end = nl ? nl - data : n;
         const int64_t next = end + 1;
         while (end > i && data[end - 1] == '\r') --end;
+        if (has_cr && end > i && std::memchr(data + i, '\r', (size_t)(end - i))) return -3;   // a lone CR inside a line
         if (end > i) {
             if (first && data[i] == '@') return -2;
             first = false;

@@ -210,7 +210,7 @@ def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
         "junk_before": "hello\n>a\nAC\n>b\nGT", "spaces": ">a\n ACGT \nAC GT\t\n>b  \nTT\n", "empty": "", "blank": "\n\n",
         "noname": ">\nACGT\n> \nGG\n", "gt_inside": ">a\nAC>GT\n>b\nTT\n", "fastq": "@q1\nACGT\n+\nIIII\n",
         "no_final_newline": ">a\nACGT", "only_header": ">a", "iupac": ">a\nACGTRYKMnnxx-*\n", "tabname": ">a\tdesc\nAC\n",
-        "indent_header": "  >a\nAC\n", "blank_first": "  \n>a\nAC\n", "cr_only_lines": ">a\r\n\r\nAC\r\r\n",
+        "lone_cr": "\r> >C\nAC\rGT\n>b\nTT\n", "lone_cr_seq": ">a\nAC\rGT\n", "indent_header": "  >a\nAC\n", "blank_first": "  \n>a\nAC\n", "cr_only_lines": ">a\r\n\r\nAC\r\r\n",
     }
     for name, text in cases.items():
         p = tmp_path / f"{name}.fa"
