@@ -538,7 +538,11 @@ __device__ __forceinline__ void softmax_pv32_exact(const _Float16* __restrict__ 
     // CU on the diffuse checkpoints against the fast path's 188 k: every 16-key step through its own branches 246 k; this form
     // 230 k (a branch ends the block the compiler schedules across, so each pass exposes its LDS reads and its score-MFMA chain,
     // which the fast path's single basic block hides under the previous pass); a tile-by-tile software pipeline that issues the
-    // next tile's score MFMAs inside the current tile's block 283 k (105 spilled registers).  profiles/r04/attention_paths.txt.
+    // next tile's score MFMAs inside the current tile's block 283 k (105 spilled registers); this form with the next pass's K
+    // operands read one pass ahead 245 k (41 spills); with the next pass's scores and maxima at the END of each block, so that
+    // they share a basic block with this pass's exponentials: 121 spills (the score tiles become loop-carried values of both
+    // branches).  What the exact path costs over the fast one is control flow, and hipcc's register allocation across it.
+    // profiles/r04/attention_paths.txt.
     auto lane_max8 = [&](const f32x16& t, const int st) {
         float a = fmaxf(fmaxf(t[8 * st], t[8 * st + 1]), t[8 * st + 2]);
         a = fmaxf(fmaxf(a, t[8 * st + 3]), t[8 * st + 4]);
