@@ -146,8 +146,11 @@ def test_standalone_submodule_operators(case):
     y = st.decoder(h.to(dev))
     ref_y = O.decoder(sd, cfg, h)
     assert y.shape == (B, 250, 1)
-    assert np.array_equal(y[..., 0].cpu().numpy() == 0, ref_y.numpy() == 0) or np.abs(ref_y.numpy()[(y[..., 0].cpu().numpy() == 0) != (ref_y.numpy() == 0)]).max() < 1e-5
-    assert np.abs(y[..., 0].cpu().numpy() - ref_y.numpy()).max() < 3 * tol
+    yn, rn = y[..., 0].cpu().numpy(), ref_y.numpy()
+    mism = (yn == 0) != (rn == 0)
+    print(f"STANDALONE {eng.mode}: decoder zero-pattern mismatches {int(mism.sum())} of {mism.size}, max |diff| {np.abs(yn - rn).max():.3e}")
+    assert not mism.any()
+    assert np.abs(yn - rn).max() < 3 * tol
     # and chained use still continues the encoder's launch (the tensors of one fused launch, no second one)
     codes = torch.from_numpy(case["g"]["codes"].astype(np.int64))
     onehot = torch.zeros(*codes.shape, 5)
@@ -518,11 +521,11 @@ def test_edge_inputs_and_parameters(mode, over):
     assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
     y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
     assert np.isfinite(y).all()
-    # a sample the noise pushes to within rounding of 0 may clamp on one side only: allow that where |ref| is tiny
     mism = (y == 0) != (r == 0)
-    assert (np.abs(r[mism]) < 1e-3).all() and (np.abs(y[mism]) < 1e-3).all() and mism.mean() < 1e-3
+    assert not mism.any()                                          # (measured: 0 of 4,250 in every case; round 3 allowed 1e-3 of them)
     d = np.abs(y - r)
-    assert d.mean() < MAE_TOL and d.max() < 5e-3, (d.mean(), d.max())
+    print(f"EDGE {mode} {over}: mae {d.mean():.3e} max {d.max():.3e} mismatches {int(mism.sum())} of {mism.size}, |ref| there <= {np.abs(r[mism]).max() if mism.any() else 0:.2e}")
+    assert d.mean() < MAE_TOL and d.max() < MAX_TOL, (d.mean(), d.max())      # (measured: <= 5.2e-5 / 2.5e-4)
     eng.close()
 
 
@@ -563,7 +566,8 @@ def test_other_layer_counts(mode, enc_l, dec_l, pre_l):
     y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
     assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
     assert np.array_equal(y == 0, r == 0)
-    assert np.abs(y - r).mean() < MAE_TOL * max(1, dec_l / 2) and np.abs(y - r).max() < MAX_TOL * max(1, dec_l / 2)
+    print(f"LAYERS {mode} enc {enc_l} dec {dec_l} pre {pre_l}: mae {np.abs(y - r).mean():.3e} max {np.abs(y - r).max():.3e}")
+    assert np.abs(y - r).mean() < MAE_TOL and np.abs(y - r).max() < MAX_TOL      # the same bound for any depth (measured: <= 5.3e-5 / 2.9e-4 with 4 + 4 layers)
     eng.close()
 
 
