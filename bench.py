@@ -244,9 +244,7 @@ def _timed_steps(eng, bases_d, nv_d, sig, dur, params, steps):
 
 def _stats_fields(st):
     return {"softmax_redo_rate": st["redo_rate"], "in_kernel_clock_ghz": st["in_kernel_clock_ghz"],
-            "cycles_per_chunk_and_cu": st["cycles_per_chunk_and_cu"],
-            "attention_steps_hi_only_share": (st["steps_hi_only"] / st["steps_classified"]) if st["steps_classified"] else None,
-            "attention_steps_skipped_share": (st["steps_skipped"] / st["steps_classified"]) if st["steps_classified"] else None}
+            "cycles_per_chunk_and_cu": st["cycles_per_chunk_and_cu"]}
 
 
 def config4_k6_leg(mode, dev, steps):

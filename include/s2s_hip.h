@@ -279,10 +279,9 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
  *   0  the FAST path: shift = the row's maximum over its first 64 keys + 2 log2 units, no maximum in later passes, straight-line
  *      code; a head whose later keys beat that shift by more than the f16 range is detected by its row sum and redone by an
  *      out-of-line online softmax (maximum and rescale in every pass).  Best for diffuse attention (the synthetic checkpoints: 0.006 - 2 % of the heads are redone);
- *   1  the EXACT path at once: running row maximum, rows re-centred only when a new score beats it by more than 8 units, and
- *      every 16-key step classified by its largest shifted score -- below -32 the step is skipped, below -16 it runs without
- *      the P_lo halves.  More attention work than the fast path when nothing classifies, far less than "fast, then redo"
- *      when most heads overflow (sharply peaked attention).  A kernel instance of its own.
+ *   1  the EXACT path at once: the online softmax (running row maximum raised and sums rescaled in every 64-key pass, no
+ *      branch) as the only path of its own kernel instance: 17 % more shader cycles than the fast path on diffuse attention,
+ *      the same time for ANY weights -- "fast, then redo" costs 1.5 - 1.7 x once most heads overflow (sharply peaked attention).
  * s2s_create chooses by a calibration launch on a fixed pseudo-random batch (exact when more than a quarter of its heads had to
  * be redone; the environment variable S2S_ATTENTION_PATH=fast|exact skips the launch); `calibration_redo_rate` returns that
  * share (-1 when no calibration ran).  Results are deterministic per chunk for a given path. */
@@ -297,8 +296,7 @@ int s2s_get_attention_path(const s2s_handle* h, int32_t* path, double* calibrati
  *   [2] ... of them redone on the safe path (0 in S2S_MODE_F32, which has no fast path),
  *   [3] shader-clock cycles (s_memtime) and [4] 100 MHz ticks (s_memrealtime) of one thread per workgroup over the whole
  *       kernel, summed over [5] workgroups: [3] / [4] / 10 is the clock in GHz the SIMDs really ran at,
- *   [6] 16-key attention steps run without the P_lo product, [7] skipped entirely, [8] classified in all (0 unless the
- *       heads ran on the exact attention path: s2s_set_attention_path), [9] reserved (0). */
+ *   [6] chunks launched on the exact attention path (s2s_set_attention_path), [7..9] reserved (0). */
 int s2s_stats_read(s2s_handle* h, uint64_t* out10);
 
 /* Diagnostic builds (-DS2S_DIAG, never the shipped library): per wave of a workgroup (8 rows) 48 per-phase shader-cycle sums

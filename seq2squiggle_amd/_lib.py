@@ -41,54 +41,40 @@ def lib():
                            "there is no CPU fallback for the predict path")
     L = C.CDLL(LIB)
     vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
-    L.s2s_blob_floats.restype = C.c_size_t
-    L.s2s_blob_floats.argtypes = [C.POINTER(S2SConfig)]
-    L.s2s_create.restype = i32
-    L.s2s_create.argtypes = [C.POINTER(S2SConfig), vp, C.c_size_t, i32, C.POINTER(vp)]
-    L.s2s_destroy.restype = None
-    L.s2s_destroy.argtypes = [vp]
-    L.s2s_last_error.restype = C.c_char_p
-    L.s2s_last_error.argtypes = [vp]
-    L.s2s_predict_chunks.restype = i32
-    L.s2s_predict_chunks.argtypes = [vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp, vp, vp, vp,
-                                     C.POINTER(S2SDebug)]
-    L.s2s_predict_packed.restype = i32
-    L.s2s_predict_packed.argtypes = [vp, vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp]
-    L.s2s_export_reads.restype = i32
-    L.s2s_export_reads.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, i64, f32, f32, f32, i32]
-    L.s2s_svb_encode.restype = i32
-    L.s2s_svb_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp]
-    L.s2s_philox_u32.restype = i32
-    L.s2s_philox_u32.argtypes = [vp, vp, u64, u32, u32, u32, u32, i32, vp]
-    L.s2s_set_profiling.restype = i32
-    L.s2s_set_profiling.argtypes = [vp, i32]
-    L.s2s_get_kernel_ms.restype = i32
-    L.s2s_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
-    L.s2s_stats_read.restype = i32
-    L.s2s_stats_read.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.s2s_set_attention_path.restype = i32
-    L.s2s_set_attention_path.argtypes = [vp, i32]
-    L.s2s_get_attention_path.restype = i32
-    L.s2s_get_attention_path.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
-    L.s2s_diag_read.restype = i32
-    L.s2s_diag_read.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.s2s_blow5_pack_bound.restype = i64
-    L.s2s_blow5_pack_bound.argtypes = [i64, i32]
-    L.s2s_blow5_pack.restype = i64
-    L.s2s_blow5_pack.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64]
-    L.s2s_compress_rows.restype = i64
-    L.s2s_compress_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, i64, vp]
-    L.s2s_sampler_replay.restype = i64
-    L.s2s_sampler_replay.argtypes = [vp, vp, i32, vp, vp, i64, i64, i64, u64, i64, i32, i32, i32, i64, vp, vp]
-    L.s2s_sampler_replay_law.restype = i64
-    L.s2s_sampler_replay_law.argtypes = [vp, vp, i32, vp, vp, i64, i64, i64, u64, i64, i32, i32, i32, i64, i32, vp, vp]
-    L.s2s_length_law.restype = i64
-    L.s2s_length_law.argtypes = [i32, u32, C.c_double, i64]
-    L.s2s_fastq_clean.restype = i64
-    L.s2s_fastq_clean.argtypes = [vp, i64, i32, vp, vp, vp, i64]
-    L.s2s_fasta_count.restype = i64
-    L.s2s_fasta_count.argtypes = [vp, i64]
-    L.s2s_fasta_clean.restype = i64
-    L.s2s_fasta_clean.argtypes = [vp, i64, i32, vp, vp, vp, i64]
+    lenient = "S2S_HIP_LIB" in os.environ     # an explicitly selected variant (A/B against an older build): entry points it lacks stay unbound
+
+    def bind(name, restype, argtypes):
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            if lenient:
+                return
+            raise
+        fn.restype, fn.argtypes = restype, argtypes
+    bind("s2s_blob_floats", C.c_size_t, [C.POINTER(S2SConfig)])
+    bind("s2s_create", i32, [C.POINTER(S2SConfig), vp, C.c_size_t, i32, C.POINTER(vp)])
+    bind("s2s_destroy", None, [vp])
+    bind("s2s_last_error", C.c_char_p, [vp])
+    bind("s2s_predict_chunks", i32, [vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp, vp, vp, vp,
+                                     C.POINTER(S2SDebug)])
+    bind("s2s_predict_packed", i32, [vp, vp, vp, vp, vp, i64, i32, C.POINTER(S2SParams), vp, vp])
+    bind("s2s_export_reads", i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, i64, f32, f32, f32, i32])
+    bind("s2s_svb_encode", i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp])
+    bind("s2s_philox_u32", i32, [vp, vp, u64, u32, u32, u32, u32, i32, vp])
+    bind("s2s_set_profiling", i32, [vp, i32])
+    bind("s2s_get_kernel_ms", i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)])
+    bind("s2s_stats_read", i32, [vp, C.POINTER(C.c_uint64)])
+    bind("s2s_set_attention_path", i32, [vp, i32])
+    bind("s2s_get_attention_path", i32, [vp, C.POINTER(i32), C.POINTER(C.c_double)])
+    bind("s2s_diag_read", i32, [vp, C.POINTER(C.c_uint64)])
+    bind("s2s_blow5_pack_bound", i64, [i64, i32])
+    bind("s2s_blow5_pack", i64, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64])
+    bind("s2s_compress_rows", i64, [vp, vp, i32, i32, i32, i32, vp, i64, vp])
+    bind("s2s_sampler_replay", i64, [vp, vp, i32, vp, vp, i64, i64, i64, u64, i64, i32, i32, i32, i64, vp, vp])
+    bind("s2s_sampler_replay_law", i64, [vp, vp, i32, vp, vp, i64, i64, i64, u64, i64, i32, i32, i32, i64, i32, vp, vp])
+    bind("s2s_length_law", i64, [i32, u32, C.c_double, i64])
+    bind("s2s_fastq_clean", i64, [vp, i64, i32, vp, vp, vp, i64])
+    bind("s2s_fasta_count", i64, [vp, i64])
+    bind("s2s_fasta_clean", i64, [vp, i64, i32, vp, vp, vp, i64])
     _lib = L
     return L

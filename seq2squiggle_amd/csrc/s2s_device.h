@@ -95,10 +95,10 @@ __shared__ unsigned long long s2s_diag_lds[8 * S2S_DIAG_SLOTS];
 #define S2S_STAT_CYCLES 1        // shader-clock cycles (s_memtime) of thread 0, summed over the workgroups
 #define S2S_STAT_TICKS 2         // 100 MHz ticks (s_memrealtime) over the same spans
 #define S2S_STAT_WGS 3           // workgroups summed
-#define S2S_STAT_TILES_HI 4      // attention tile classification (S2S_MODE_F16X3 with classification on): 16-key steps run without P_lo
-#define S2S_STAT_TILES_SKIP 5    //   ... skipped altogether
-#define S2S_STAT_TILES 6         //   ... classified in all
-__shared__ unsigned s2s_stats_lds[12];      // [0] redo, [1..3] tile classes (hi-only, skipped, all), [4..7] entry stamps
+#define S2S_STAT_RSV0 4          // (three reserved counters: round 4's step classification used them; the kernel still folds the
+#define S2S_STAT_RSV1 5          //  -- always zero -- LDS words: removing those three guarded atomics from the epilogue moved hipcc's
+#define S2S_STAT_RSV2 6          //  schedule of the fast instance from 188.5 k to 191.3 k cycles per chunk, A/B in one call)
+__shared__ unsigned s2s_stats_lds[12];      // [0] redo, [1..3] reserved, [4..7] entry stamps
 
 #ifdef S2S_TILEHIST
 // diagnostic build: histogram of the largest shifted score (log2 units below the row's pass-0 maximum) per attention tile,

@@ -489,147 +489,19 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
         }
     }
 }
-// The EXACT path of the 32x32x16 core: what every head runs when the handle
-// says so (s2s_fused_kernel<.., EXACT = true>, s2s_set_attention_path; s2s_create picks it for weights whose calibration launch redoes more
-// than a quarter of its heads).  Same operands, same two-MFMA scores with the shift in the k-slots, but
-//  * the shift is the row's exact running maximum (no head-room bias): pass 0 takes it like the fast path; a later pass of 64 keys takes its
-//    lane maxima anyway (below) and only if some row's new score beats its shift by more than 8 log2 units
-//    (wave-uniform branch, rare) are the rows re-centred on their new maxima -- O scaled by exp2(old - new), the pass's scores
-//    lowered by the same amount.  The new shift is what its two f16 halves really encode, so the factor and the shift agree to the last bit;
-//  * with the row maximum in hand every 16-key step is CLASSIFIED by its largest shifted score (4 v_max3 per lane, one compare, the
-//    wave's verdict in vcc): nothing above -32 -- every P of the step is below 2^-32 of a row sum that is at least 1: the step is
-//    skipped (no exponentials, no split, no P.V); nothing above -16 -- the P_lo halves are below 2^-27 of the row sum: the
-//    step runs hi-only (no v_fma_mix, one P.V MFMA instead of two).  Peaked attention is exactly where the fast path fails and
-//    where most steps classify (profiles/r04/tile_hist.txt).
-// n_hi / n_skip: wave-uniform counts of the steps that took the shorter routes (production counters, s2s_stats_read).
-#ifndef S2S_EXACT_RECENTRE
-#define S2S_EXACT_RECENTRE 8.0f
-#endif
-#ifndef S2S_T_SKIP
-#define S2S_T_SKIP (-32.0f)
-#endif
-#ifndef S2S_T_HI
-#define S2S_T_HI (-16.0f)
-#endif
-template <int TV, bool LO>
-__device__ __forceinline__ void softmax_pv32_exact(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
-                                                   const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O,
-                                                   unsigned& n_hi, unsigned& n_skip) {
-    constexpr int NT = 8;
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto k_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp + 32 * t * 8); };
-    auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
-    O = zero16;
-    h8 qb2m = qb2;
-    float m = 0.0f;                                                       // the shift qb2m carries: exactly -(hi + lo)
-    auto set_shift = [&](const float m_new) {
-        const float nm = -m_new;
-        const _Float16 nh = (_Float16)nm;
-        const _Float16 nl = (_Float16)(nm - (float)nh);
-        const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, nl}));
-        uv4 q2 = __builtin_bit_cast(uv4, qb2);
-        q2[0] = h ? pk : q2[0];
-        qb2m = __builtin_bit_cast(h8, q2);
-        return -((float)nh + (float)nl);                                  // 22 significant bits: exact in fp32
-    };
-    // 64 keys per pass, like the fast path, and for a pass in which nothing classifies and no row needs re-centring -- ONE
-    // wave-uniform branch after the lane maxima -- the fast path's straight-line body, which hipcc interleaves well; the
-    // classified variant (a branch or two per 16-key step) only where it pays.  Measured on the way, shader cycles per chunk and
-    // CU on the diffuse checkpoints against the fast path's 188 k: every 16-key step through its own branches 246 k; this form
-    // 230 k (a branch ends the block the compiler schedules across, so each pass exposes its LDS reads and its score-MFMA chain,
-    // which the fast path's single basic block hides under the previous pass); a tile-by-tile software pipeline that issues the
-    // next tile's score MFMAs inside the current tile's block 283 k (105 spilled registers); this form with the next pass's K
-    // operands read one pass ahead 245 k (41 spills); with the next pass's scores and maxima at the END of each block, so that
-    // they share a basic block with this pass's exponentials: 121 spills (the score tiles become loop-carried values of both
-    // branches).  What the exact path costs over the fast one is control flow, and hipcc's register allocation across it.
-    // profiles/r04/attention_paths.txt.
-    auto lane_max8 = [&](const f32x16& t, const int st) {
-        float a = fmaxf(fmaxf(t[8 * st], t[8 * st + 1]), t[8 * st + 2]);
-        a = fmaxf(fmaxf(a, t[8 * st + 3]), t[8 * st + 4]);
-        a = fmaxf(fmaxf(a, t[8 * st + 5]), t[8 * st + 6]);
-        return fmaxf(a, t[8 * st + 7]);
-    };
-#pragma unroll
-    for (int h2 = 0; h2 < NT / 2; ++h2) {
-        h8 ka[2], kb[2], va[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ka[i] = k_of(2 * h2 + i);
-            kb[i] = *reinterpret_cast<const h8*>(kp2 + (2 * h2 + i) * (h ? 0 : 32 * 8));
-            va[i][0] = v_of(2 * h2 + i, 0); va[i][1] = v_of(2 * h2 + i, 1);
-        }
-        SB_ATT();
-        f32x16 sc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
-        if (TV < 256 && h2 == NT / 2 - 1) {                               // phantom keys -> -inf: rows 224 + .. >= TV of the last tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (224 + (r & 3) + 8 * (r >> 2) + 4 * h >= TV) sc[1][r] = -__builtin_inff();
-        }
-        float mx[2][2] = {{lane_max8(sc[0], 0), lane_max8(sc[0], 1)}, {lane_max8(sc[1], 0), lane_max8(sc[1], 1)}};
-        if (h2 == 0) {                                                    // the first shift: the row maxima of the first 64 keys
-            const float rm = max_h(fmaxf(fmaxf(mx[0][0], mx[0][1]), fmaxf(mx[1][0], mx[1][1])));
-            m = set_shift(rm);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) mx[i][st] -= rm;           // (the classification below: exact enough)
-        }
-        const float lm = fmaxf(fmaxf(mx[0][0], mx[0][1]), fmaxf(mx[1][0], mx[1][1]));
-        const bool recentre = h2 > 0 && __any(lm > S2S_EXACT_RECENTRE);
-        const bool plain = !recentre && (!LO || (__any(mx[0][0] > S2S_T_HI) && __any(mx[0][1] > S2S_T_HI) &&
-                                                 __any(mx[1][0] > S2S_T_HI) && __any(mx[1][1] > S2S_T_HI)));
-        if (__builtin_expect(plain, 1)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
-                    exp_split4<LO>(f32x4{sc[i][8 * st], sc[i][8 * st + 1], sc[i][8 * st + 2], sc[i][8 * st + 3]}, one, h0, h1, l0, l1);
-                    exp_split4<LO>(f32x4{sc[i][8 * st + 4], sc[i][8 * st + 5], sc[i][8 * st + 6], sc[i][8 * st + 7]}, one, h2_, h3, l2, l3);
-                    O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
-                    if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
-                }
-        } else {
-            if (recentre) {                                               // some row's new score beats its shift by > 8 units
-                const float rm = max_h(lm);                               // the row's maximum over this pass: both lane halves agree
-                const float m_enc = set_shift(m + fmaxf(rm, 0.0f));
-                const float d = m_enc - m;                                // (0 for a row whose maximum did not rise)
-                O *= __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    sc[i] -= d;
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) mx[i][st] -= d;
-                }
-                m = m_enc;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    if (!__any(mx[i][st] > S2S_T_SKIP)) { ++n_skip; continue; }
-                    const f32x4 s0 = {sc[i][8 * st], sc[i][8 * st + 1], sc[i][8 * st + 2], sc[i][8 * st + 3]};
-                    const f32x4 s1 = {sc[i][8 * st + 4], sc[i][8 * st + 5], sc[i][8 * st + 6], sc[i][8 * st + 7]};
-                    unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
-                    if (!LO || __any(mx[i][st] > S2S_T_HI)) {
-                        exp_split4<LO>(s0, one, h0, h1, l0, l1);
-                        exp_split4<LO>(s1, one, h2_, h3, l2, l3);
-                        O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
-                        if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
-                    } else {
-                        exp_split4<false>(s0, one, h0, h1, l0, l1);
-                        exp_split4<false>(s1, one, h2_, h3, l2, l3);
-                        O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
-                        ++n_hi;
-                    }
-                }
-        }
-    }
-}
+// The EXACT attention path (s2s_fused_kernel<.., EXACT = true>, s2s_set_attention_path; s2s_create picks it for weights whose
+// calibration launch redoes more than a quarter of its heads) is softmax_pv32<TV, SAFE = true> above -- the textbook online
+// softmax, running maximum raised and sums rescaled in every 64-key pass, branch-free -- as the ONLY path of its kernel
+// instance: 221.5 k shader cycles per chunk and CU on every checkpoint, whatever the weights, where "fast path, then redo" costs
+// 188.6 k on diffuse attention and 279-325 k once most heads overflow.  Three cleverer exact paths were built in round 4 and lost
+// to it (LABNOTES.md, profiles/r04/attention_paths_*.txt; their code is in commits 3a2cca9 and the two after b739589):
+//  * exact running maximum with lazy re-centring and every 16-key step CLASSIFIED by its largest shifted score (skipped below
+//    -32, P_lo dropped below -16): 229-251 k, 224 k with 51 % of the steps skipped.  The verdict has to be wave-uniform, i.e. a
+//    branch per pass, and a branch ends the basic block hipcc schedules across -- each pass then exposes its LDS reads and its
+//    score-MFMA chain -- which costs more (27 k) than the skipped steps save;
+//  * four other schedules of that path (per-step branches 246 k; a tile pipeline 283 k with 105 spilled registers; K operands a
+//    pass ahead 245 k; next pass's scores at the end of each block: 121 spills);
+//  * two passes over the keys, branch-free (all row maxima first, then the fast path's body with the exact shift): 280 k, 93 spills.
 // the constant rows behind the V region (see AttnLdsH): called once per kernel, before the first barrier
 template <class G> __device__ __forceinline__ void att32_consts(char* __restrict__ lds, const int tid, const int nthreads) {
     if constexpr (G::ATT32) {
@@ -814,14 +686,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     const _Float16* vp = (n < 16 ? Vl + (head * 16 + n) * G::VS : n == 16 ? crow : (n >= 20 && n < 28 && !S2S_ONE_ZEROS_ROW) ? zrow2 : crow + G::VS) + 8 * hl;
                     f32x16 O;
                     float lsum;
-                    if constexpr (EXACT && S2S_ATT32_MSLOT) {              // the handle's attention path is "exact" (its own kernel instance)
-                        unsigned n_hi = 0, n_skip = 0;
-                        softmax_pv32_exact<TV, LO>(kp, kp2, vp, qb1, qb2, one, hl, O, n_hi, n_skip);
+                    if constexpr (EXACT) {                                 // the handle's attention path is "exact" (its own kernel instance)
+                        softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
                         lsum = sum_h(O[8]);                                // row 16 lives in the lower lane half
-                        if (lane == 0) {                                   // production counters (s2s_stats_read)
-                            if (n_hi) atomicAdd(&s2s_stats_lds[1], n_hi);
-                            if (n_skip) atomicAdd(&s2s_stats_lds[2], n_skip);
-                        }
                     } else {
                     softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, kp2, vp, qb1, qb2, one, hl, O, pf_src ? 1 : 0);
                     lsum = sum_h(O[8]);

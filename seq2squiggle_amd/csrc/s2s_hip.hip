@@ -468,7 +468,7 @@ template <int MODE> struct Fused {
 // TEST = false is the production instance: no injected variates and no stage outputs, whose address arithmetic would otherwise
 // sit (and spill) in the hot loop; the parity tests that inject or ask for stage outputs run the TEST = true instance of the
 // same code.
-// EXACT: the decoder attention's exact path (s2s_device_h.h: softmax_pv32_exact) instead of "fast path, redone on overflow" -- a
+// EXACT: the decoder attention's exact path (the online softmax, s2s_device_h.h) instead of "fast path, redone on overflow" -- a
 // kernel instance of its own, so that neither path's registers and schedule depend on the other (split-f16 modes only).
 template <int MODE, bool TEST, bool EXACT = false>
 __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         if (threadIdx.x < S2S_PROG_INTS + S2S_Z2_FLOATS)              // (and the second zeros row behind them)
             reinterpret_cast<int*>(lds_raw + DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS) * 4)[threadIdx.x] = 0;
     }
-    if (threadIdx.x == 0) {                // production counters: redo count, tile classes, entry stamps (kept in LDS, not in SGPRs, across the kernel)
+    if (threadIdx.x == 0) {                // production counters: redo count, entry stamps (kept in LDS, not in SGPRs, across the kernel)
         const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
         s2s_stats_lds[0] = 0; s2s_stats_lds[1] = 0; s2s_stats_lds[2] = 0; s2s_stats_lds[3] = 0;
         s2s_stats_lds[4] = (unsigned)c0; s2s_stats_lds[5] = (unsigned)(c0 >> 32);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         for (int i = threadIdx.x; i < 8 * S2S_DIAG_SLOTS; i += DEC_WAVES * 64)
             if (s2s_diag_lds[i]) atomicAdd(dbg.diag + i, s2s_diag_lds[i]);        // [wave][slot], summed over the workgroups
 #endif
-    __syncthreads();                       // every wave's redo / tile counts are in LDS
+    __syncthreads();                       // every wave's redo count is in LDS
 #ifdef S2S_TILEHIST
     if (dbg.diag)
         for (int i = threadIdx.x; i < 2 * 2 * 64; i += DEC_WAVES * 64)
@@ -599,9 +599,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         const unsigned long long c0 = ((unsigned long long)s2s_stats_lds[5] << 32) | s2s_stats_lds[4];
         const unsigned long long r0 = ((unsigned long long)s2s_stats_lds[7] << 32) | s2s_stats_lds[6];
         if (s2s_stats_lds[0]) atomicAdd(dbg.stats + S2S_STAT_REDO, (unsigned long long)s2s_stats_lds[0]);
-        if (s2s_stats_lds[1]) atomicAdd(dbg.stats + S2S_STAT_TILES_HI, (unsigned long long)s2s_stats_lds[1]);
-        if (s2s_stats_lds[2]) atomicAdd(dbg.stats + S2S_STAT_TILES_SKIP, (unsigned long long)s2s_stats_lds[2]);
-        if (s2s_stats_lds[3]) atomicAdd(dbg.stats + S2S_STAT_TILES, (unsigned long long)s2s_stats_lds[3]);
+        if (s2s_stats_lds[1]) atomicAdd(dbg.stats + S2S_STAT_RSV0, (unsigned long long)s2s_stats_lds[1]);
+        if (s2s_stats_lds[2]) atomicAdd(dbg.stats + S2S_STAT_RSV1, (unsigned long long)s2s_stats_lds[2]);
+        if (s2s_stats_lds[3]) atomicAdd(dbg.stats + S2S_STAT_RSV2, (unsigned long long)s2s_stats_lds[3]);
         atomicAdd(dbg.stats + S2S_STAT_CYCLES, __builtin_readcyclecounter() - c0);
         atomicAdd(dbg.stats + S2S_STAT_TICKS, __builtin_amdgcn_s_memrealtime() - r0);
         atomicAdd(dbg.stats + S2S_STAT_WGS, 1ull);
@@ -1125,7 +1125,7 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
 
 // Which softmax path the split-f16 decoder tries first is a property of the WEIGHTS: one launch of 512 pseudo-random chunks with the
 // default samplers on the fast path counts the heads it had to redo (the production counters); above a quarter the handle starts
-// every head on the exact path (s2s_device_h.h: softmax_pv32_exact).  A fixed input, so the same weights always get the same
+// every head on the exact path (s2s_device_h.h: the online softmax as its own kernel instance).  A fixed input, so the same weights always get the same
 // answer, on any device.  The export scratch inside the slab holds the launch's buffers.
 static int calibrate_attention(s2s_handle* h) {
     if (h->cfg.compute_mode == S2S_MODE_F32) return S2S_OK;
@@ -1506,8 +1506,7 @@ int s2s_stats_read(s2s_handle* h, uint64_t* out10) {
     out10[1] = (uint64_t)h->stat_chunks * DEC_WAVES * S2S_HEADS * (uint64_t)h->cfg.decoder_layers;
     out10[2] = raw[S2S_STAT_REDO];
     out10[3] = raw[S2S_STAT_CYCLES]; out10[4] = raw[S2S_STAT_TICKS]; out10[5] = raw[S2S_STAT_WGS];
-    out10[6] = raw[S2S_STAT_TILES_HI]; out10[7] = raw[S2S_STAT_TILES_SKIP];
-    out10[8] = (uint64_t)h->stat_exact_chunks * DEC_WAVES * S2S_HEADS * (uint64_t)h->cfg.decoder_layers * 16; out10[9] = 0;
+    out10[6] = (uint64_t)h->stat_exact_chunks; out10[7] = 0; out10[8] = 0; out10[9] = 0;
     h->stat_chunks = 0; h->stat_exact_chunks = 0;
     return S2S_OK;
 }

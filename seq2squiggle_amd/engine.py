@@ -279,10 +279,10 @@ class Engine:
         the share of softmax runs redone on the safe path and the clock the SIMDs held are data dependent."""
         out = (C.c_uint64 * 10)()
         self._check(_lib.lib().s2s_stats_read(self._h, out), "s2s_stats_read")
-        chunks, runs, redo, cyc, ticks, wgs, t_hi, t_skip, t_all, _ = (int(x) for x in out)
+        chunks, runs, redo, cyc, ticks, wgs, exact_chunks = (int(x) for x in out[:7])
         return {"chunks": chunks, "softmax_runs": runs, "softmax_redone": redo,
                 "redo_rate": (redo / runs) if runs else 0.0,
                 "in_kernel_clock_ghz": (cyc / ticks * 0.1) if ticks else None,
                 "cycles_per_chunk_and_cu": (cyc / chunks) if chunks else None,    # a workgroup owns its CU: sum of their cycles / chunks
                 "shader_cycles": cyc, "ticks_100mhz": ticks, "workgroups": wgs,
-                "steps_hi_only": t_hi, "steps_skipped": t_skip, "steps_classified": t_all}
+                "chunks_on_exact_path": exact_chunks}

@@ -30,7 +30,7 @@ def P(**kw):
                 ids=lambda p: "-".join(p))
 def case(request):
     """(checkpoint, arithmetic[, attention path]): the committed checkpoints calibrate to the fast softmax path; the "exact"
-    cases run every test of this file on the other one too (s2s_set_attention_path: running maximum, step classification)."""
+    cases run every test of this file on the other one too (s2s_set_attention_path: the online softmax as the only path)."""
     tag, mode = request.param[:2]
     sd, cfg = load_ckpt(tag)
     eng = S.Engine(sd, cfg, mode=mode)
@@ -234,13 +234,12 @@ def test_peaked_attention_forces_the_rescale_fallback(mode, scale):
         assert st["chunks"] == bases.shape[0] and st["softmax_runs"] == bases.shape[0] * 8 * 8 * 2
         assert 1.0 < st["in_kernel_clock_ghz"] < 2.6 and st["workgroups"] == min(256, bases.shape[0])
         if mode == "f32":
-            assert st["softmax_redone"] == 0 and st["steps_classified"] == 0
+            assert st["softmax_redone"] == 0 and st["chunks_on_exact_path"] == 0
         elif path == "fast":               # ... saw the rare branch (the out-of-line online softmax)
             assert 0.5 * st["softmax_runs"] < st["softmax_redone"] <= st["softmax_runs"], st
-            assert st["steps_classified"] == 0
-        else:                              # exact path at once: nothing to redo, every step classified, many of them skipped
-            assert st["softmax_redone"] == 0 and st["steps_classified"] == 16 * st["softmax_runs"]
-            assert st["steps_skipped"] > 0.05 * st["steps_classified"], st
+            assert st["chunks_on_exact_path"] == 0
+        else:                              # exact path at once: nothing to redo
+            assert st["softmax_redone"] == 0 and st["chunks_on_exact_path"] == st["chunks"]
         assert eng.stats()["chunks"] == 0  # read-and-reset
         assert np.isfinite(y).all()
         same = ((y == 0) == (t == 0))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Both decoder attention paths (s2s_set_attention_path: fast / exact) on the committed checkpoints and on sharpened ones:
-speed (chunks/s, shader cycles per chunk and CU from the kernel's own counters, redo / step-class shares) on 1000 x 5 kb reads,
+speed (chunks/s, shader cycles per chunk and CU from the kernel's own counters, redo share) on 1000 x 5 kb reads,
 and error against an fp64 evaluation of the oracle on the golden chunks (the fp32 oracle's own error beside it).
     tools/attn_paths.py [n_reads]          (S2S_HIP_LIB selects a library variant)"""
 import json, os, sys, time
@@ -59,14 +59,13 @@ for tag, k, scales in (("k9", 9, (1 / 3.0, 1.0, 2.0, 4.0, 16.0)), ("k6", 6, (1.0
             st = eng.stats()
             row = {"checkpoint": tag, "wq_wk_scale": round(scale, 4), "path": path, "calibrated": auto, "calibration_redo_rate": eng.calibration_redo_rate,
                    "chunks_per_sec": 3 * b.shape[0] / el, "cycles_per_chunk_and_cu": st["cycles_per_chunk_and_cu"], "clock_ghz": st["in_kernel_clock_ghz"],
-                   "redo_rate": st["redo_rate"], "hi_only": st["steps_hi_only"] / max(1, st["steps_classified"]),
-                   "skipped": st["steps_skipped"] / max(1, st["steps_classified"]),
+                   "redo_rate": st["redo_rate"],
                    "mae_vs_fp64": float(np.abs(y - r64)[same].mean()), "max_vs_fp64": float(np.abs(y - r64)[same].max()),
                    "fp32_oracle_mae_vs_fp64": float(np.abs(r32 - r64)[ok].mean()), "fp32_oracle_max_vs_fp64": float(np.abs(r32 - r64)[ok].max()),
                    "zero_pattern_equal": float(same.mean())}
             rows.append(row)
             print(f"{tag} x{scale:<6.3g} {path:5s} (calibrated: {auto}, redo at calibration {eng.calibration_redo_rate:.4f}): {row['chunks_per_sec'] / 1e6:.3f} M chunks/s, "
-                  f"{row['cycles_per_chunk_and_cu'] / 1e3:.1f} k cycles at {row['clock_ghz']:.3f} GHz, redo {row['redo_rate']:.4f}, hi-only {row['hi_only']:.3f}, skipped {row['skipped']:.3f} | "
+                  f"{row['cycles_per_chunk_and_cu'] / 1e3:.1f} k cycles at {row['clock_ghz']:.3f} GHz, redo {row['redo_rate']:.4f} | "
                   f"MAE vs fp64 {row['mae_vs_fp64']:.2e} (max {row['max_vs_fp64']:.2e}); fp32 oracle {row['fp32_oracle_mae_vs_fp64']:.2e} (max {row['fp32_oracle_max_vs_fp64']:.2e})", flush=True)
         eng.close()
 print("ATTNPATHSJSON " + json.dumps(rows))
