@@ -59,6 +59,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_PRIO_MODE
 #define S2S_PRIO_MODE 4      // 4: the two waves of a SIMD balance their progress through the attention loop (prio_balance); 0: off (A/B builds)
 #endif
+#ifndef S2S_ONLINE2
+#define S2S_ONLINE2 1           // the exact instance runs softmax_pv32_online (0: the fast instance's out-of-line fallback, A/B)
+#endif
 #ifndef S2S_ONE_ZEROS_ROW
 #define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
 #endif
@@ -502,6 +505,73 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 //  * four other schedules of that path (per-step branches 246 k; a tile pipeline 283 k with 105 spilled registers; K operands a
 //    pass ahead 245 k; next pass's scores at the end of each block: 121 spills);
 //  * two passes over the keys, branch-free (all row maxima first, then the fast path's body with the exact shift): 280 k, 93 spills.
+// softmax_pv32_online: that online softmax with the fast path's operand tricks -- the shift rides in the k-slots of the second
+// score MFMA (no 16-register C operand), a pass's scores are ISSUED AGAIN with the raised shift instead of being lowered by 32
+// subtractions (the matrix pipe has the room), and only accumulator registers 0-8 are rescaled (rows 17-31 of O are zeros).
+template <int TV, bool LO>
+__device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
+                                                    const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
+    constexpr int NT = 8;
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto k_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp + 32 * t * 8); };
+    auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
+    O = zero16;
+    h8 qb2m = qb2;
+    float m = 0.0f;                                                       // the shift qb2m carries: exactly -(hi + lo)
+#pragma unroll
+    for (int h2 = 0; h2 < NT / 2; ++h2) {
+        h8 ka[2], kb[2], va[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ka[i] = k_of(2 * h2 + i);
+            kb[i] = *reinterpret_cast<const h8*>(kp2 + (2 * h2 + i) * (h ? 0 : 32 * 8));
+            va[i][0] = v_of(2 * h2 + i, 0); va[i][1] = v_of(2 * h2 + i, 1);
+        }
+        SB_ATT();
+        f32x16 sc[2];
+        auto score_pass = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
+            if (TV < 256 && h2 == NT / 2 - 1) {                           // phantom keys -> -inf: rows 224 + .. >= TV of the last tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (224 + (r & 3) + 8 * (r >> 2) + 4 * h >= TV) sc[1][r] = -__builtin_inff();
+            }
+        };
+        score_pass();
+        float mh = sc[0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mh = fmaxf(mh, sc[i][r]);
+        mh = max_h(mh);                                                   // the row's maximum over this pass, relative to the shift
+        const float nm = -(h2 == 0 ? mh : m + fmaxf(mh, 0.0f));
+        const _Float16 nh = (_Float16)nm;
+        const _Float16 nl = (_Float16)(nm - (float)nh);
+        const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, nl}));
+        uv4 q2 = __builtin_bit_cast(uv4, qb2);
+        q2[0] = h ? pk : q2[0];
+        qb2m = __builtin_bit_cast(h8, q2);
+        const float m_enc = -((float)nh + (float)nl);                     // what the two halves encode: exact in fp32
+        if (h2 > 0) {
+            const float f = __builtin_amdgcn_exp2f(m - m_enc);            // (1 for a row whose maximum did not rise)
+#pragma unroll
+            for (int r = 0; r < 9; ++r) O[r] *= f;
+        }
+        m = m_enc;
+        score_pass();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+                exp_split4<LO>(f32x4{sc[i][8 * st], sc[i][8 * st + 1], sc[i][8 * st + 2], sc[i][8 * st + 3]}, one, h0, h1, l0, l1);
+                exp_split4<LO>(f32x4{sc[i][8 * st + 4], sc[i][8 * st + 5], sc[i][8 * st + 6], sc[i][8 * st + 7]}, one, h2_, h3, l2, l3);
+                O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
+                if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
+            }
+    }
+}
 // the constant rows behind the V region (see AttnLdsH): called once per kernel, before the first barrier
 template <class G> __device__ __forceinline__ void att32_consts(char* __restrict__ lds, const int tid, const int nthreads) {
     if constexpr (G::ATT32) {
@@ -687,7 +757,11 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     f32x16 O;
                     float lsum;
                     if constexpr (EXACT) {                                 // the handle's attention path is "exact" (its own kernel instance)
+#if S2S_ONLINE2 && S2S_ATT32_MSLOT
+                        softmax_pv32_online<TV, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
+#else
                         softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
+#endif
                         lsum = sum_h(O[8]);                                // row 16 lives in the lower lane half
                     } else {
                     softmax_pv32<TV, S2S_ALWAYS_RESCALE != 0, LO>(kp, kp2, vp, qb1, qb2, one, hl, O, pf_src ? 1 : 0);
