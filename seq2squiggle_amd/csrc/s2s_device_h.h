@@ -493,11 +493,12 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     }
 }
 // The EXACT attention path (s2s_fused_kernel<.., EXACT = true>, s2s_set_attention_path; s2s_create picks it for weights whose
-// calibration launch redoes more than a quarter of its heads) is softmax_pv32<TV, SAFE = true> above -- the textbook online
-// softmax, running maximum raised and sums rescaled in every 64-key pass, branch-free -- as the ONLY path of its kernel
-// instance: 221.5 k shader cycles per chunk and CU on every checkpoint, whatever the weights, where "fast path, then redo" costs
-// 188.6 k on diffuse attention and 279-325 k once most heads overflow.  Three cleverer exact paths were built in round 4 and lost
-// to it (LABNOTES.md, profiles/r04/attention_paths_*.txt; their code is in commits 3a2cca9 and the two after b739589):
+// calibration launch redoes more than 12 % of its heads) is the online softmax -- running maximum raised and sums rescaled in
+// every 64-key pass, branch-free -- as the ONLY path of its kernel instance: the same shader cycles per chunk on every
+// checkpoint, whatever the weights, where "fast path, then redo" costs 188.6 k on diffuse attention and 279-325 k once most
+// heads overflow.  As softmax_pv32<TV, SAFE = true> (the fast instance's out-of-line fallback) it measured 221.7 k; as
+// softmax_pv32_online below 206.5 k.  Three cleverer exact paths were built in round 4 and lost to it (LABNOTES.md,
+// profiles/r04/attention_paths_*.txt; their code is in commits 3a2cca9 and the two after b739589):
 //  * exact running maximum with lazy re-centring and every 16-key step CLASSIFIED by its largest shifted score (skipped below
 //    -32, P_lo dropped below -16): 229-251 k, 224 k with 51 % of the steps skipped.  The verdict has to be wave-uniform, i.e. a
 //    branch per pass, and a branch ends the basic block hipcc schedules across -- each pass then exposes its LDS reads and its
