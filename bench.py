@@ -59,7 +59,7 @@ def pmc_counters(mode, chunks_per_launch):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(path)).get(mode, {})
-            k = next(k for k in d if "fused" in k)
+            k = max((k for k in d if "fused" in k), key=lambda k: d[k].get("_launch", {}).get("chunks", 0))   # (not the 512-chunk calibration launch)
             c = d[k]
             chunks = c.get("_launch", {}).get("chunks", 32768)
             per_chunk = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / chunks

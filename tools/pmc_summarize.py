@@ -22,7 +22,9 @@ for arg in sys.argv[1:]:
             k[row["Counter_Name"]] = float(row["Counter_Value"])
             k.setdefault("_launch", {"grid": int(row["Grid_Size"]), "workgroup": int(row["Workgroup_Size"]),
                                      "scratch_bytes_per_lane": int(row["Scratch_Size"]), "vgprs": int(row["VGPR_Count"]),
-                                     "lds_bytes": int(row["LDS_Block_Size"]), **({"chunks": int(chunks)} if chunks else {})})
+                                     "lds_bytes": int(row["LDS_Block_Size"]),
+                                     # (the TEST instance of the fused kernel is s2s_create's calibration launch: 512 chunks)
+                                     **({"chunks": 512 if "s2s_fused_kernel<" in name and ", true" in name.split(">")[0] else int(chunks)} if chunks else {})})
     # wall time of that first dispatch in every pass (pmcN_kernel_trace.csv), so that a counter can be turned into a rate: the
     # clock the chip held in the pass that counted GRBM_GUI_ACTIVE is GRBM_GUI_ACTIVE / 8 XCDs / that pass's duration
     for path in sorted(glob.glob(os.path.join(d, "pmc*_kernel_trace.csv"))):
