@@ -95,10 +95,11 @@ __shared__ unsigned long long s2s_diag_lds[8 * S2S_DIAG_SLOTS];
 #define S2S_STAT_CYCLES 1        // shader-clock cycles (s_memtime) of thread 0, summed over the workgroups
 #define S2S_STAT_TICKS 2         // 100 MHz ticks (s_memrealtime) over the same spans
 #define S2S_STAT_WGS 3           // workgroups summed
-#define S2S_STAT_RSV0 4          // (three reserved counters: round 4's step classification used them; the kernel still folds the
-#define S2S_STAT_RSV1 5          //  -- always zero -- LDS words: removing those three guarded atomics from the epilogue moved hipcc's
-#define S2S_STAT_RSV2 6          //  schedule of the fast instance from 188.5 k to 191.3 k cycles per chunk, A/B in one call)
-__shared__ unsigned s2s_stats_lds[12];      // [0] redo, [1..3] reserved, [4..7] entry stamps
+// (256 bytes, not 48: the kernel's dynamic LDS follows this array, and every bank-slot placement in s2s_device_h.h -- V^T row r on
+//  16-byte slot r mod 16, the zeros rows beside them -- assumes that its base is a multiple of 256 bytes, i.e. of the 64 banks;
+//  with a 48-byte array in front SQ_LDS_BANK_CONFLICT went from 4.3 k back to 8.4 k cycles per chunk (profiles/r04/lds_conflicts.txt;
+//  the wall clock was the same: 188.6 k shader cycles at 2.195 GHz against 190.9 k at 2.215 GHz -- the chip is power-limited))
+__shared__ __attribute__((aligned(256))) unsigned s2s_stats_lds[64];      // [0] redo, [4..7] entry stamps
 
 #ifdef S2S_TILEHIST
 // diagnostic build: histogram of the largest shifted score (log2 units below the row's pass-0 maximum) per attention tile,

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
     }
     if (threadIdx.x == 0) {                // production counters: redo count, entry stamps (kept in LDS, not in SGPRs, across the kernel)
         const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
-        s2s_stats_lds[0] = 0; s2s_stats_lds[1] = 0; s2s_stats_lds[2] = 0; s2s_stats_lds[3] = 0;
+        s2s_stats_lds[0] = 0;
         s2s_stats_lds[4] = (unsigned)c0; s2s_stats_lds[5] = (unsigned)(c0 >> 32);
         s2s_stats_lds[6] = (unsigned)r0; s2s_stats_lds[7] = (unsigned)(r0 >> 32);
     }
@@ -599,9 +599,6 @@ __global__ __launch_bounds__(DEC_WAVES * 64, DEC_WPS) void s2s_fused_kernel(
         const unsigned long long c0 = ((unsigned long long)s2s_stats_lds[5] << 32) | s2s_stats_lds[4];
         const unsigned long long r0 = ((unsigned long long)s2s_stats_lds[7] << 32) | s2s_stats_lds[6];
         if (s2s_stats_lds[0]) atomicAdd(dbg.stats + S2S_STAT_REDO, (unsigned long long)s2s_stats_lds[0]);
-        if (s2s_stats_lds[1]) atomicAdd(dbg.stats + S2S_STAT_RSV0, (unsigned long long)s2s_stats_lds[1]);
-        if (s2s_stats_lds[2]) atomicAdd(dbg.stats + S2S_STAT_RSV1, (unsigned long long)s2s_stats_lds[2]);
-        if (s2s_stats_lds[3]) atomicAdd(dbg.stats + S2S_STAT_RSV2, (unsigned long long)s2s_stats_lds[3]);
         atomicAdd(dbg.stats + S2S_STAT_CYCLES, __builtin_readcyclecounter() - c0);
         atomicAdd(dbg.stats + S2S_STAT_TICKS, __builtin_amdgcn_s_memrealtime() - r0);
         atomicAdd(dbg.stats + S2S_STAT_WGS, 1ull);
