@@ -275,11 +275,13 @@ def weight_sensitivity_leg(mode, bases_d, nv_d, sig, dur, params, steps):
     heads whose later keys beat the first 64 keys' maximum by more than the f16 range, and the chip's clock under the kernel
     follows the operands.  Same workload as the headline, decoder w_qs / w_ks (weights and biases) of the committed k = 9
     checkpoint scaled: x 1/3 is torch's default init, x 1 the committed checkpoint (the headline), x 4 and x 16 the sharpened
-    ones of tests/test_gpu_parity.py::test_peaked_attention_forces_the_rescale_fallback."""
+    ones of tests/test_gpu_parity.py::test_peaked_attention_forces_the_rescale_fallback.  `attention_path` is what s2s_create's
+    calibration launch chose for those weights (include/s2s_hip.h: s2s_set_attention_path); the k = 6 checkpoint is the
+    `config4_k6` object."""
     sd0, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
     rows = []
     for scale, name in ((1.0 / 3.0, "default init (committed / 3)"), (1.0, "committed synthetic_k9.ckpt (headline)"),
-                        (4.0, "committed x 4"), (16.0, "committed x 16")):
+                        (2.0, "committed x 2"), (4.0, "committed x 4"), (8.0, "committed x 8"), (16.0, "committed x 16")):
         sd = {k: v.clone() for k, v in sd0.items()}
         for k in sd:
             if k.startswith("decoders.") and k.endswith(("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")):
@@ -287,7 +289,7 @@ def weight_sensitivity_leg(mode, bases_d, nv_d, sig, dur, params, steps):
         eng = S.Engine(sd, cfg, device=bases_d.device.index, mode=mode)
         rate, st, ms = _timed_steps(eng, bases_d, nv_d, sig, dur, params, steps)
         rows.append({"decoder_wq_wk_scale": scale, "checkpoint": name, "chunks_per_sec": rate, "avg_launch_ms": ms,
-                     "attention_path": getattr(eng, "attention_path", None), **_stats_fields(st)})
+                     "attention_path": eng.attention_path, "calibration_redo_rate": eng.calibration_redo_rate, **_stats_fields(st)})
         eng.close()
     rates = [r["chunks_per_sec"] for r in rows]
     return {"workload": "the headline's resident batch, decoder w_qs / w_ks scaled", "rows": rows,
