@@ -81,6 +81,9 @@ def version():
 @click.option("-v", "--verbosity", type=click.Choice(["debug", "info", "warning", "error"], case_sensitive=False), default="info")
 @click.option("--compute-mode", default="f16x3", type=click.Choice(["f16x3", "f32", "f16"]), hidden=True,
               help="Decoder arithmetic of the MI355X engine.")
+@click.option("--attention-path", default="auto", type=click.Choice(["auto", "fast", "exact"]), hidden=True,
+              help="Softmax path of the split-f16 decoder: auto = chosen per checkpoint by the engine's calibration launch "
+                   "(include/s2s_hip.h: s2s_set_attention_path); exact = the same time whatever the weights.")
 @click.option("--gpus", default=1, type=int, hidden=True,
               help="Run on this many GPUs of the node: one process per GPU, the read set sharded, one OUT.rankN file per process "
                    "(the same as starting the command under torchrun --nproc-per-node N).")
@@ -90,9 +93,12 @@ def version():
 def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profile, show_advanced_options, noise_sampler,
             duration_sampler, dwell_mean, dwell_std, noise_std, distr, predict_batch_size, export_every_n_samples,
             sample_rate, bps, digitisation, range_val, offset_mean, offset_std, median_before_mean, median_before_std,
-            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode, gpus, keep_shards):
+            min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode, attention_path,
+            gpus, keep_shards):
     """Generate nanopore signals from a reference genome (default) or from reads (--read-input)."""
     import os
+    if attention_path != "auto":
+        os.environ["S2S_ATTENTION_PATH"] = attention_path          # read by s2s_create (also in the ranks --gpus starts)
     if gpus > 1 and "WORLD_SIZE" not in os.environ:
         # The reference leaves multi-GPU runs to Lightning (devices="auto", DDP: inference.py:430-445); here the command starts its
         # own ranks as CHILD processes -- before anything in this process has touched the GPU -- and returns their exit code.
