@@ -27,5 +27,8 @@ def test_host_library_under_sanitizers(which, runtime, tmp_path):
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), which, "24"], capture_output=True, text=True,
                        env=env, timeout=900, cwd=ROOT)
     tail = (r.stdout + r.stderr)[-4000:]
+    for cannot_start in ("unexpected memory mapping", "Shadow memory range interleaves", "failed to allocate", "ReserveShadowMemoryRange failed"):
+        if cannot_start in tail:           # the sanitizer runtime itself cannot run on this kernel / address-space layout
+            pytest.skip(f"{runtime} cannot start here: {cannot_start}")
     assert r.returncode == 0 and f"FUZZ_OK {which}" in r.stdout and f"SANITIZE_OK {which}" in r.stdout, tail
     assert "ERROR: AddressSanitizer" not in tail and "runtime error:" not in tail and "WARNING: ThreadSanitizer" not in tail, tail
