@@ -281,11 +281,15 @@ def weight_sensitivity_leg(mode, bases_d, nv_d, sig, dur, params, steps):
     sd0, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
     rows = []
     for scale, name in ((1.0 / 3.0, "default init (committed / 3)"), (1.0, "committed synthetic_k9.ckpt (headline)"),
-                        (2.0, "committed x 2"), (4.0, "committed x 4"), (8.0, "committed x 8"), (16.0, "committed x 16")):
+                        (2.0, "committed x 2"), (4.0, "committed x 4"), (8.0, "committed x 8"), (16.0, "committed x 16"),
+                        (None, "positional: decoder w_qs = w_ks = 2 I, biases 0 (scores follow the sinusoid table: local attention)")):
         sd = {k: v.clone() for k, v in sd0.items()}
         for k in sd:
             if k.startswith("decoders.") and k.endswith(("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")):
-                sd[k] *= scale
+                if scale is not None:
+                    sd[k] *= scale
+                else:                      # a structured case beside the scaled random ones: q.k = 4 x.x', dominated by position_enc
+                    sd[k] = 2.0 * torch.eye(64) if k.endswith("weight") else torch.zeros(64)
         eng = S.Engine(sd, cfg, device=bases_d.device.index, mode=mode)
         rate, st, ms = _timed_steps(eng, bases_d, nv_d, sig, dur, params, steps)
         rows.append({"decoder_wq_wk_scale": scale, "checkpoint": name, "chunks_per_sec": rate, "avg_launch_ms": ms,

@@ -283,7 +283,7 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
  *      branch; the shift in the score MFMA's k-slots, a pass's scores issued again with the raised shift) as the only path of
  *      its own kernel instance: 9.5 % more shader cycles than the fast path on diffuse attention, the same time for ANY
  *      weights -- "fast, then redo" costs 1.5 - 1.7 x once most heads overflow (sharply peaked attention).
- * s2s_create chooses by a calibration launch on a fixed pseudo-random batch (exact when more than 12 % of its heads had to
+ * s2s_create chooses by a calibration launch on a fixed pseudo-random batch (exact when more than 8 % of its heads had to
  * be redone; the environment variable S2S_ATTENTION_PATH=fast|exact skips the launch); `calibration_redo_rate` returns that
  * share (-1 when no calibration ran).  Results are deterministic per chunk for a given path. */
 int s2s_set_attention_path(s2s_handle* h, int32_t path);

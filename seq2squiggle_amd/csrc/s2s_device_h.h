@@ -493,7 +493,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     }
 }
 // The EXACT attention path (s2s_fused_kernel<.., EXACT = true>, s2s_set_attention_path; s2s_create picks it for weights whose
-// calibration launch redoes more than 12 % of its heads) is the online softmax -- running maximum raised and sums rescaled in
+// calibration launch redoes more than 8 % of its heads) is the online softmax -- running maximum raised and sums rescaled in
 // every 64-key pass, branch-free -- as the ONLY path of its kernel instance: the same shader cycles per chunk on every
 // checkpoint, whatever the weights, where "fast path, then redo" costs 188.6 k on diffuse attention and 279-325 k once most
 // heads overflow.  As softmax_pv32<TV, SAFE = true> (the fast instance's out-of-line fallback) it measured 221.7 k; as

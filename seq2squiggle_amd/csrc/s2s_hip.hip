@@ -1121,7 +1121,7 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
                         const float* inject_z01, float* out_signal, int32_t* out_dur, const s2s_debug* dbg);
 
 // Which softmax path the split-f16 decoder tries first is a property of the WEIGHTS: one launch of 512 pseudo-random chunks with the
-// default samplers on the fast path counts the heads it had to redo (the production counters); above 12 % the handle starts
+// default samplers on the fast path counts the heads it had to redo (the production counters); above 8 % the handle starts
 // every head on the exact path (s2s_device_h.h: the online softmax as its own kernel instance).  A fixed input, so the same weights always get the same
 // answer, on any device.  The export scratch inside the slab holds the launch's buffers.
 static int calibrate_attention(s2s_handle* h) {
@@ -1149,7 +1149,9 @@ static int calibrate_attention(s2s_handle* h) {
     const int rs = s2s_stats_read(h, st);
     if (rs != S2S_OK) return rs;
     h->calib_redo_rate = st[1] ? (double)st[2] / (double)st[1] : 0.0;
-    h->attn_exact = h->calib_redo_rate > 0.12 ? 1 : 0;   // (measured break-even: 188.6 + 138 r = 206.5 k cycles per chunk at r = 0.13, profiles/r04/attention_paths.txt)
+    // (measured: a redone head also holds its seven partner waves at the next barrier, so a redo share r costs ~ 200 k x r cycles per
+    //  chunk while r is small -- 1.7 %: + 3.2 k, 10.4 %: + 22.8 k -- and 153 k x r once most heads redo; the exact instance costs + 19.8 k)
+    h->attn_exact = h->calib_redo_rate > 0.08 ? 1 : 0;
     return S2S_OK;
 }
 
