@@ -130,6 +130,31 @@ __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h
     lo = __builtin_bit_cast(h4, (uv2{l0, l1}));
 }
 
+// Key ORDER inside the decoder's K and V^T images (ATT32 layout): the blocks of four consecutive keys are dealt out over the
+// four 64-key passes of the attention loop -- pass j holds the key blocks b = j (mod 4), i.e. keys 4j .. 4j+3, 16+4j .., 32+4j ..
+// -- so that pass 0, whose row maxima are the fast path's softmax shift, is a sample of the WHOLE row instead of its first 64
+// keys.  A softmax does not care about the order of its keys; the images are written in this order (an address, nothing
+// else), the loop is unchanged.  What it buys (tools/redo_model.py, the share of heads the fast path has to redo): decoder
+// w_qs / w_ks x 2: 55 % -> 7 %; attention on the positional encoding (w_qs = w_ks = 2 I): 9 % -> 0.2 %, (3 I): 29 % -> 9 %.
+// Inside pass j the blocks are rotated by j & 1, so that the 16 lanes of a K store (keys 16 T .. 16 T + 15, four of them in each
+// pass) still spread over eight 8-byte bank slots (2-way, as in the natural order) instead of four.
+// position of key (T, c) = 16 T + c:  64 j + 4 ((T + (j & 1)) & 15) + (c & 3) with j = c >> 2;  key at position p:
+__host__ __device__ constexpr int att32_key_at(const int p) {
+    return 16 * ((((p & 63) >> 2) - ((p >> 6) & 1)) & 15) + 4 * (p >> 6) + (p & 3);
+}
+// phantom keys (>= TV) -> -inf in the score tile `tile` (a compile-time index; h: the lane half)
+template <int TV>
+__device__ __forceinline__ void att32_mask_tile(f32x16& t, const int tile, const int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const bool p0 = att32_key_at(32 * tile + row) >= TV, p1 = att32_key_at(32 * tile + row + 4) >= TV;   // lane halves 0 / 1
+        if (p0 && p1) t[r] = -__builtin_inff();
+        else if (p1) t[r] = h ? -__builtin_inff() : t[r];
+        else if (p0) t[r] = h ? t[r] : -__builtin_inff();
+    }
+}
+
 // LDS of the f16 block: K [head][hi|lo][key][8 d] halves, V^T [head][16 rows: 0-7 hi d, 8-15 lo d][VS keys]
 // halves, and a per-wave scratch for the Q^T operand re-layout.
 template <int NQ, int WAVES, int NKT = 16> struct AttnLdsH {
@@ -355,12 +380,9 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     auto scores = [&](const h8 ka, const f32x16 c0) { return MFMAW(ka, qb2, MFMAW(ka, qb1, c0)); };
     O = zero16;
     auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
-    auto mask_last = [&](f32x16& t) {                                    // phantom keys -> -inf: rows 224 + .. >= TV of the last tile
-        if (TV < 256) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (224 + (r & 3) + 8 * (r >> 2) + 4 * h >= TV) t[r] = -__builtin_inff();
-        }
+    auto mask_pass = [&](f32x16 (&t)[2], const int h2) {                  // phantom keys -> -inf (att32_key_at: they sit in tiles 5 and 6)
+        att32_mask_tile<TV>(t[0], 2 * h2, h);
+        att32_mask_tile<TV>(t[1], 2 * h2 + 1, h);
     };
     auto pv = [&](const f32x16& t, const h8 (&va)[2]) {                   // O += [V_hi; V_lo; 1] . exp2(t), 16 keys per MFMA
 #pragma unroll
@@ -396,7 +418,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
             f32x16 sc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
-            if (h2 == NT / 2 - 1) mask_last(sc[1]);
+            mask_pass(sc, h2);
             if (h2 == 0) {
                 float mh = sc[0][0];
 #pragma unroll
@@ -416,7 +438,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
             f32x16 sc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm);     // (pass 0: negm = 0)
-            if (h2 == NT / 2 - 1) mask_last(sc[1]);
+            mask_pass(sc, h2);
             if (h2 == 0) {
                 float mh = sc[0][0];
 #pragma unroll
@@ -475,7 +497,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
             f32x16 sc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) sc[i] = scores(ka[i], negm);     // (pass 0: negm = 0)
-            if (h2 == NT / 2 - 1) mask_last(sc[1]);
+            mask_pass(sc, h2);
             float mh = sc[0][0];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -533,11 +555,8 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
         auto score_pass = [&]() {
 #pragma unroll
             for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
-            if (TV < 256 && h2 == NT / 2 - 1) {                           // phantom keys -> -inf: rows 224 + .. >= TV of the last tile
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (224 + (r & 3) + 8 * (r >> 2) + 4 * h >= TV) sc[1][r] = -__builtin_inff();
-            }
+            att32_mask_tile<TV>(sc[0], 2 * h2, h);                        // phantom keys -> -inf (they sit in tiles 5 and 6)
+            att32_mask_tile<TV>(sc[1], 2 * h2 + 1, h);
         };
         score_pass();
         float mh = sc[0][0];
@@ -681,13 +700,16 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int T = qt0 + q;
-            const int key = 16 * T + c;
+            const int key = G::ATT32 ? 64 * (c >> 2) + 4 * ((T + ((c >> 2) & 1)) & 15) + (c & 3) : 16 * T + c;      // (ATT32: the position, see att32_key_at)
             h4 hi, lo;
             split4<LO>(ak[q], one, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 1) * G::KEYS + key) * 8 + d0) = lo;
             split4<LO>(av[q], one, hi, lo);                           // 4 consecutive keys of one V^T row: one b64 store each
-            const int vcol = G::ATT32 ? 16 * T + 8 * (g & 1) + 4 * (g >> 1)
+            // (ATT32: this lane's four keys are key block 4 T + g, at block position 16 g + Tr, Tr = (T + (g & 1)) & 15: 16-key step
+            //  4 g + (Tr >> 2), block Tr & 3 of it)
+            const int Tr = (T + (g & 1)) & 15;
+            const int vcol = G::ATT32 ? 16 * (4 * g + (Tr >> 2)) + 8 * (Tr & 1) + 4 * ((Tr >> 1) & 1)
                            : G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
             *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
