@@ -607,13 +607,16 @@ def test_other_layer_counts(mode, enc_l, dec_l, pre_l):
     g = torch.rand(B, 16, generator=gen) * 25
     z = torch.randn(B, 250, generator=gen)
     ref = O.predict_chunks(sd, cfg, codes, O.PredictParams(**P()), inject_g=g, inject_z01=z)
-    out = eng.predict_chunks(torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), S.PredictParams(**P()),
-                             inject_g=g.cuda(), inject_z01=z.cuda())
-    y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
-    assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
-    assert np.array_equal(y == 0, r == 0)
-    print(f"LAYERS {mode} enc {enc_l} dec {dec_l} pre {pre_l}: mae {np.abs(y - r).mean():.3e} max {np.abs(y - r).max():.3e}")
-    assert np.abs(y - r).mean() < MAE_TOL and np.abs(y - r).max() < MAX_TOL      # the same bound for any depth (measured: <= 5.3e-5 / 2.9e-4 with 4 + 4 layers)
+    for path in (("fast", "exact") if mode == "f16x3" else ("fast",)):           # both attention paths of the split-f16 block
+        if mode == "f16x3":
+            eng.attention_path = path
+        out = eng.predict_chunks(torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), S.PredictParams(**P()),
+                                 inject_g=g.cuda(), inject_z01=z.cuda())
+        y, r = out["signal"].cpu().numpy(), ref["signal"].numpy()
+        assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy())
+        assert np.array_equal(y == 0, r == 0)
+        print(f"LAYERS {mode} {path} enc {enc_l} dec {dec_l} pre {pre_l}: mae {np.abs(y - r).mean():.3e} max {np.abs(y - r).max():.3e}")
+        assert np.abs(y - r).mean() < MAE_TOL and np.abs(y - r).max() < MAX_TOL  # the same bound for any depth (measured: <= 5.3e-5 / 2.9e-4 with 4 + 4 layers)
     eng.close()
 
 
