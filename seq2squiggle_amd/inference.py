@@ -437,6 +437,12 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
         load_model.on_predict_epoch_end()
     torch.cuda.synchronize(load_model.device)
     logger.info(f"Predicted {n_chunks} chunks ({n_chunks * 250} padded samples).")
+    if logger.isEnabledFor(logging.DEBUG):     # how THESE weights behaved on the kernel (s2s_stats_read; the read resets the counters)
+        eng = load_model.engine
+        st = eng.stats()
+        logger.debug(f"attention path {eng.attention_path} (calibration launch: {100 * eng.calibration_redo_rate:.2f} % of the heads redone); "
+                     f"this run: {100 * st['redo_rate']:.3f} % redone, {st['in_kernel_clock_ghz'] or 0:.2f} GHz in the kernel, "
+                     f"{st['cycles_per_chunk_and_cu'] or 0:.0f} cycles per chunk and CU")
     shard = rank_output_path(str(out), rank, world)
     if world > 1 and not os.path.exists(shard) and hasattr(writer, "write_records"):
         # a rank without reads (more ranks than reads) still leaves its -- empty -- shard, so that the rank files always merge
