@@ -357,7 +357,10 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
 
     The leg must never cost the headline line: its barriers and its gather run on a gloo group of their own with a short timeout
     (a rank that died would otherwise hold the others in an RCCL barrier for ten minutes), a rank whose run raises still reaches
-    both barriers and reports the error, and the output directory is chosen by free space (1.3 GB per rank and pass)."""
+    both barriers and reports the error, and the output directory is chosen by free space (1.3 GB per rank and pass).
+
+    Then the part a sharded run owes the reference's ONE output file: rank 0 joins the rank files (`merge_seconds`, `with_merge`),
+    and runs the user-facing command `predict --gpus N` itself once (`one_command`: its launch, predict and merge seconds)."""
     import shutil
     import tempfile
     from datetime import timedelta
@@ -368,7 +371,7 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
     fasta = os.path.join(ROOT, "tests", "golden", "example_lambda_genome.fasta")
     grp = dist.new_group(backend="gloo", timeout=timedelta(seconds=300))
     n_total = 12500 * world
-    need = 1.6e9 * int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    need = 3.0e9 * int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))     # rank files + the merged file, twice over (the leg, then the command)
     choice = [None]
     if rank == 0:
         for d in ("/dev/shm", tempfile.gettempdir()):
@@ -380,7 +383,7 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
     if out_dir is None:
         return {"skipped": f"no directory with {need / 1e9:.0f} GB free for the rank shard files"} if rank == 0 else None
 
-    def run():
+    def run(keep):
         td = tempfile.mkdtemp(dir=out_dir)
         err, own, chunks, size = None, 0.0, 0, 0
         try:
@@ -405,28 +408,102 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
             dist.barrier(group=grp)
             wall = time.perf_counter() - t0
         finally:
-            shutil.rmtree(td, ignore_errors=True)
-        return own, wall, chunks, size, err
-    first_pass = run()                     # the first call pays the process's one-time costs (pinned buffers, thread pools)
-    own, wall, chunks, size, err = run() if first_pass[4] is None else first_pass
+            if not keep or err:
+                shutil.rmtree(td, ignore_errors=True)
+        return own, wall, chunks, size, err, td
+    first_pass = run(False)                # the first call pays the process's one-time costs (pinned buffers, thread pools)
+    own, wall, chunks, size, err, td = run(True) if first_pass[4] is None else first_pass
     rows = [None] * world
-    dist.all_gather_object(rows, (own, wall, float(chunks), float(size), float(cpu_share()), err), group=grp)
+    try:
+        dist.all_gather_object(rows, (own, wall, float(chunks), float(size), float(cpu_share()), err, td), group=grp)
+        errs = [r[5] for r in rows if r[5]]
+        merged, command = None, None
+        if rank == 0 and not errs:
+            # the ONE file the reference leaves (inference.py:65-79): rank 0 joins the rank files while the others wait -- as the
+            # parent of `predict --gpus N` does once its ranks have exited, with the whole CPU quota for its copy threads
+            try:
+                from seq2squiggle_amd.parallel import rank_output_path
+                from seq2squiggle_amd.signal_io import merge_shards
+                shards = [rank_output_path(os.path.join(rows[r][6], "o.blow5"), r, world) for r in range(world)]
+                threads = max(1, cpu_share() * int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+                t1 = time.perf_counter()
+                n_rec = merge_shards(shards, os.path.join(td, "merged.blow5"), threads=threads, consume=True)
+                merged = dict(merge_shards.last, seconds=time.perf_counter() - t1, records=n_rec, threads=threads)
+            except Exception as e:
+                merged = {"error": f"{type(e).__name__}: {e}"}
+            shutil.rmtree(td, ignore_errors=True)              # (room for the command below)
+            os.makedirs(td, exist_ok=True)
+            command = one_command(mode, world, n_total, fasta, td)
+        dist.barrier(group=grp)                                # nobody removes a rank file before rank 0 has joined them
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
     dist.destroy_process_group(grp)
     if rank != 0:
         return None
-    errs = [r[5] for r in rows if r[5]]
     if errs:
         return {"error": errs}
     wall = max(r[1] for r in rows)
     total = sum(r[2] for r in rows)
-    return {"workload": f"example lambda genome -n {n_total} -r 5000 -> out.rankN.blow5 on {out_dir}: "
-                        f"BASELINE configs[2]'s per-GPU share on each of {world} ranks, sharded by inference_run",
-            "seconds": wall, "chunks": total, "chunks_per_sec": total / wall, "reads_per_sec": n_total / wall,
-            "per_rank_seconds": [r[0] for r in rows], "per_rank_chunks": [r[2] for r in rows],
-            "per_rank_cpu_share_threads": [int(r[4]) for r in rows], "output_bytes": sum(r[3] for r in rows),
-            "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
-            "includes": "per rank: FASTA parse, sampler skip-ahead to its shard, engine creation, chunking, kernels, export, D2H, "
-                        "compression on cpu_share threads, file write"}
+    out = {"workload": f"example lambda genome -n {n_total} -r 5000 -> out.rankN.blow5 on {out_dir}: "
+                       f"BASELINE configs[2]'s per-GPU share on each of {world} ranks, sharded by inference_run",
+           "seconds": wall, "chunks": total, "chunks_per_sec": total / wall, "reads_per_sec": n_total / wall,
+           "per_rank_seconds": [r[0] for r in rows], "per_rank_chunks": [r[2] for r in rows],
+           "per_rank_cpu_share_threads": [int(r[4]) for r in rows], "output_bytes": sum(r[3] for r in rows),
+           "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
+           "includes": "per rank: FASTA parse, sampler skip-ahead to its shard, engine creation, chunking, kernels, export, D2H, "
+                       "compression on cpu_share threads, file write"}
+    if merged and "error" not in merged:
+        out["merge_seconds"] = merged["seconds"]
+        out["merge"] = {"bytes": merged.get("bytes"), "bytes_copied": merged.get("bytes_copied"), "threads": merged["threads"],
+                        "gb_per_sec": merged.get("bytes", 0) / merged["seconds"] / 1e9, "records": merged["records"],
+                        "how": "first rank file becomes the output, the record sections of the others move as byte ranges "
+                               "(copy_file_range on native threads, seq2squiggle_amd/merge.py)"}
+        out["with_merge"] = {"seconds": wall + merged["seconds"], "chunks_per_sec": total / (wall + merged["seconds"]),
+                             "reads_per_sec": n_total / (wall + merged["seconds"])}
+    elif merged:
+        out["merge"] = merged
+    if command:
+        out["one_command"] = command
+        out["launch_seconds"] = command.get("launch_seconds")
+        if "seconds" in command:
+            command["chunks_per_sec"] = total / command["seconds"]
+    return out
+
+
+def one_command(mode, world, n_total, fasta, td):
+    """The command people run: `python -m seq2squiggle_amd predict <lambda> -n N -r 5000 -o OUT.blow5 --gpus <world>` as a child of
+    rank 0, started while the bench's own ranks wait at a barrier (two processes per GPU for its duration): wall clock of the
+    whole command with its own account of launch (spawn -> the slowest rank has the interpreter, torch and the library loaded),
+    predict (-> the slowest rank has written its file) and merge seconds.  Skipped on a one-GPU rehearsal with more than two ranks
+    (the pool allows six processes on a device)."""
+    if os.environ.get("S2S_BENCH_ONE_GPU") and world > 2:
+        return {"skipped": "one-GPU rehearsal: ranks of the bench + ranks of the command would exceed the pool's process limit"}
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                        "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS") and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_"))}
+    env["S2S_TIMING_JSON"] = os.path.join(td, "timing.json")
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    if os.environ.get("S2S_BENCH_ONE_GPU"):
+        env["S2S_ONE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "seq2squiggle_amd", "predict", fasta, "-n", str(n_total), "-r", "5000", "-o",
+           os.path.join(td, "cmd.blow5"), "--gpus", str(world), "--seed", "42", "-m",
+           os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"), "--compute-mode", mode, "-v", "warning"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 200 s", "cmd": " ".join(cmd[1:])}
+    seconds = time.perf_counter() - t0
+    if p.returncode != 0:
+        return {"error": f"exit code {p.returncode}: {(p.stderr or p.stdout)[-400:]}", "cmd": " ".join(cmd[1:])}
+    out = {"cmd": "python " + " ".join(cmd[1:]).replace(ROOT + os.sep, "").replace(td + os.sep, "OUT/"), "seconds": seconds,
+           "reads_per_sec": n_total / seconds, "output_bytes": os.path.getsize(os.path.join(td, "cmd.blow5"))}
+    try:
+        with open(env["S2S_TIMING_JSON"]) as f:
+            out.update({k: v for k, v in json.load(f).items() if k.endswith("_seconds") or k in ("merge_bytes", "merge_bytes_copied", "reads")})
+    except (OSError, ValueError):
+        pass
+    return out
 
 
 WORKLOADS = {"config2": 1000, "config3": 12500}     # reads per GPU: BASELINE.json configs[1] / configs[2] (100,000 reads over 8 GPUs)
@@ -628,6 +705,9 @@ def main():
             out["end_to_end_sharded"] = sharded
             if "chunks_per_sec" in sharded:
                 out["end_to_end_sharded"]["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
+                for part in ("with_merge", "one_command"):         # ... with the merge into ONE file, and as the one command with its launch
+                    if "chunks_per_sec" in sharded.get(part, {}):
+                        sharded[part]["of_resident_rate"] = sharded[part]["chunks_per_sec"] / chunks_s
         if one_gpu:
             out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 (gloo barrier) -- NOT a scaling measurement"
         if world == 1 and not a.no_cpu_baseline:

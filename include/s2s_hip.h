@@ -274,6 +274,18 @@ int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
 int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8_t* out, int64_t* seq_offs,
                         int64_t* name_span, int64_t max_records);
 
+/* ---- host-side helpers of the rank-shard merge (no GPU work, no handle; `predict --gpus N` / `merge-shards`): the reference
+ * leaves ONE output file (inference.py:65-79, signal_io.py:167-171, 268-282), a sharded run one per rank.
+ * s2s_copy_ranges copies n byte ranges (src_fd[i], src_off[i], len[i]) -> (dst_fd[i], dst_off[i]) on `threads` threads with
+ * copy_file_range (in the kernel, no user-space buffer; pread / pwrite through a bounce buffer where the file system refuses it);
+ * ranges must not overlap inside one file.  Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the failing call).
+ * s2s_blow5_scan walks the [u64 size][body] records of a BLOW5 file between byte offsets begin and end (the end of the
+ * header and the start of the end-of-file marker) reading the size prefixes only: the record count, or -2 when the chain of
+ * sizes does not end exactly at `end` (a truncated shard). */
+int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd, const int64_t* dst_off,
+                        const int64_t* len, int32_t threads);
+int64_t s2s_blow5_scan(int32_t fd, int64_t begin, int64_t end);
+
 /* Which softmax path the split-f16 decoder attention (S2S_MODE_F16X3 / S2S_MODE_F16) tries first (layers.py:20-40 is one
  * unmasked softmax over 250 keys; both paths compute it within the parity bound):
  *   0  the FAST path: shift = the row's maximum over its first 64 keys + 2 log2 units, no maximum in later passes, straight-line

@@ -24,15 +24,39 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps())
 
 
-def compile_to(out: str, extra=(), verbose: bool = False) -> str:
-    """hipcc -> `out` with extra flags (tools build -D variants of the library this way)."""
+def compile_to(out: str, extra=(), verbose: bool = False, report: bool = False):
+    """hipcc -> `out` with extra flags (tools build -D variants of the library this way).  report=True: -> the compiler's
+    kernel-resource-usage remarks parsed per kernel (resource_usage) instead of the path."""
     os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", *extra, "-o", out,
            SRC, SRC_HOST, "-lz", "-ldl", "-lpthread"]
-    if verbose:
+    if verbose or report:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    if report:
+        return resource_usage(subprocess.run(cmd, check=True, capture_output=True, text=True).stderr)
     subprocess.run(cmd, check=True)
+    return out
+
+
+def resource_usage(remarks: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage output -> {mangled kernel name: {"VGPRs", "ScratchSize [bytes/lane]",
+    "VGPRs Spill", "SGPRs Spill", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]", ...: int}}."""
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
+        if not m:
+            continue
+        text = m.group(1)
+        if text.startswith("Function Name:"):
+            cur = out.setdefault(text.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in text:
+            key, val = text.rsplit(":", 1)
+            try:
+                cur[key.strip()] = int(val)
+            except ValueError:
+                cur[key.strip()] = val.strip()
     return out
 
 

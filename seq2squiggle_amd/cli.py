@@ -97,8 +97,6 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
             gpus, keep_shards):
     """Generate nanopore signals from a reference genome (default) or from reads (--read-input)."""
     import os
-    if attention_path != "auto":
-        os.environ["S2S_ATTENTION_PATH"] = attention_path          # read by s2s_create (also in the ranks --gpus starts)
     if gpus > 1 and "WORLD_SIZE" not in os.environ:
         # The reference leaves multi-GPU runs to Lightning (devices="auto", DDP: inference.py:430-445); here the command starts its
         # own ranks as CHILD processes -- before anything in this process has touched the GPU -- and returns their exit code.
@@ -107,16 +105,31 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
             ctx.exit(1)
         if str(out).endswith(".pod5") and os.path.exists(out) and not keep_shards:
             raise FileExistsError(f"{out} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
-        rc = _launch_ranks(gpus)
+        import time
+        t0 = time.time()
+        rc, timing = _launch_ranks(gpus)
+        timing["ranks_seconds"] = time.time() - t0
         if rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
-            # one output file, as the reference writes: the rank files are joined in rank order and removed
+            # one output file, as the reference writes (inference.py:65-79): the first rank's file becomes OUT, the payload of the
+            # others moves in as byte ranges on copy threads (merge.py), the rank files are gone afterwards
             from .parallel import rank_output_path
             from .signal_io import merge_shards as _merge
             shards = [rank_output_path(str(out), r, gpus) for r in range(gpus)]
-            n = _merge(shards, str(out))
-            for p_ in shards:
-                os.remove(p_)
-            click.echo(f"{n} reads from {gpus} ranks -> {out}")
+            t1 = time.time()
+            n = _merge(shards, str(out), consume=True)
+            timing["merge_seconds"] = time.time() - t1
+            timing["merge_bytes"] = _merge.last.get("bytes", 0)
+            timing["merge_bytes_copied"] = _merge.last.get("bytes_copied", 0)
+            timing["reads"] = n
+            launch = timing.get("launch_seconds")
+            click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {launch if launch is None else round(launch, 2)} s, "
+                       f"ranks {timing['ranks_seconds']:.2f} s in all, merge {timing['merge_seconds']:.2f} s for "
+                       f"{timing['merge_bytes'] / 1e9:.2f} GB]")
+        timing["total_seconds"] = time.time() - t0
+        if os.environ.get("S2S_TIMING_JSON") and not os.environ.get("S2S_DRY_LAUNCH"):
+            import json
+            with open(os.environ["S2S_TIMING_JSON"], "w") as f:
+                json.dump(timing, f)
         ctx.exit(rc)
     from .inference import inference_run
     from .utils import set_seeds, setup_logging
@@ -132,6 +145,8 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
     setup_logging(verbosity)
     logger.info("seq2squiggle (MI355X engine) version %s", str(__version__))
     cfg = set_config(config)
+    import time
+    t_ready = time.time()                      # interpreter, torch and the library are loaded: what a rank pays before its first read
     from .parallel import shared_seed
     seed = set_seeds(shared_seed(seed))        # --seed 0 under torchrun: rank 0's fresh seed, for every rank
     inference_run(config=cfg, saved_weights=model, fasta=str(fasta), read_input=read_input, n=num_reads, r=read_length,
@@ -141,17 +156,29 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
                   sample_rate=sample_rate, bps=bps, digitisation=digitisation, range_val=range_val,
                   offset_mean=offset_mean, offset_std=offset_std, median_before_mean=median_before_mean,
                   median_before_std=median_before_std, min_noise=min_noise, min_duration=min_duration,
-                  min_read_len=min_read_len, preserve_read_ids=preserve_read_ids, seed=seed, mode=compute_mode)
+                  min_read_len=min_read_len, preserve_read_ids=preserve_read_ids, seed=seed, mode=compute_mode,
+                  attention_path=attention_path)
     logger.info("Prediction finished.")
+    if os.environ.get("S2S_TIMING_DIR"):       # a rank of `predict --gpus N`: when it was ready and when it was done, for the parent's summary
+        import json
+        with open(os.path.join(os.environ["S2S_TIMING_DIR"], f"rank{os.environ.get('RANK', '0')}.json"), "w") as f:
+            json.dump({"ready": t_ready, "done": time.time()}, f)
 
 
-def _launch_ranks(gpus: int) -> int:
-    """`predict --gpus N` outside torchrun: the same command line under torch.distributed.run, one rank per GPU (rendezvous on
-    127.0.0.1); S2S_DRY_LAUNCH=1 prints the child command instead of running it."""
+def _launch_ranks(gpus: int):
+    """`predict --gpus N` outside torchrun: the same command line once per GPU, as N CHILD processes of this one (which never touches
+    the GPU) with the environment torchrun would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1,
+    MASTER_PORT) -- started directly: the elastic agent of torch.distributed.run costs an import of torch in the parent and a
+    rendezvous before the first rank starts, and there is nothing here for it to supervise.  The first rank that fails ends the
+    others (by their pids).  S2S_DRY_LAUNCH=1 prints the child command and environment instead of running it.
+    -> (exit code, {"launch_seconds": spawn -> the slowest rank is ready to read its input, "predict_seconds": ... -> the slowest is done})."""
     import json
     import os
+    import shutil
     import socket
     import subprocess
+    import tempfile
+    import time
     argv, skip = [], False
     for a in sys.argv[1:]:
         if skip:
@@ -166,25 +193,61 @@ def _launch_ranks(gpus: int) -> int:
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "seq2squiggle_amd"] + argv
+    cmd = [sys.executable, "-m", "seq2squiggle_amd"] + argv
+    rank_env = lambda r: {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "LOCAL_WORLD_SIZE": str(gpus),
+                          "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
     if os.environ.get("S2S_DRY_LAUNCH"):
-        click.echo(json.dumps({"dry_launch": cmd}))
-        return 0
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+        click.echo(json.dumps({"dry_launch": cmd, "rank_env": [rank_env(r) for r in range(gpus)]}))
+        return 0, {}
+    timing_dir = tempfile.mkdtemp(prefix="s2s-ranks-")
+    base = dict(os.environ, S2S_TIMING_DIR=timing_dir)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=dict(base, **rank_env(r))) for r in range(gpus)]
+    rc = 0
+    try:
+        left = set(range(gpus))
+        while left:
+            for r in sorted(left):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                left.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    logger.error(f"rank {r} exited with code {code}; ending the other ranks")
+                    for q in left:
+                        procs[q].terminate()
+            if left:
+                time.sleep(0.02)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+        timing = {}
+        try:
+            rows = [json.load(open(os.path.join(timing_dir, f))) for f in os.listdir(timing_dir)]
+            if len(rows) == gpus:
+                timing = {"launch_seconds": max(x["ready"] for x in rows) - t0,
+                          "predict_seconds": max(x["done"] for x in rows) - max(x["ready"] for x in rows)}
+        except (OSError, ValueError):
+            pass
+        shutil.rmtree(timing_dir, ignore_errors=True)
+    return rc, timing
 
 
 @main.command("merge-shards")
 @click.argument("shards", nargs=-1, required=True, type=click.Path(exists=True, dir_okay=False))
 @click.option("-o", "--out", required=True, type=click.Path(dir_okay=False), help="Merged .blow5 / .slow5 / .pod5 file.")
-def merge_shards(shards, out):
-    """Concatenate the OUT.rankN.blow5 (or .slow5 / .pod5) shard files of a multi-GPU run, in the order given, into one file.
-    (Read ids and read numbers already continue across the shards of one run.)"""
+@click.option("--threads", default=None, type=int, help="Copy threads (default: this process's CPU share).")
+@click.option("--consume", is_flag=True, help="Turn the first shard into the output and delete the others (moves 1/N fewer bytes).")
+def merge_shards(shards, out, threads, consume):
+    """Join the OUT.rankN.blow5 (or .slow5 / .pod5) shard files of a multi-GPU run, in the order given, into one file: raw byte
+    ranges on copy threads, nothing is decompressed.  (Read ids and read numbers already continue across the shards of one run.)"""
     from .signal_io import merge_shards as _merge
-    n = _merge(list(shards), out)
-    click.echo(f"{n} records -> {out}")
+    n = _merge(list(shards), out, threads=threads, consume=consume)
+    st = _merge.last
+    click.echo(f"{n} records -> {out}  [{st.get('bytes', 0) / 1e9:.3f} GB in {st.get('seconds', 0):.2f} s]")
 
 
 if __name__ == "__main__":

@@ -106,6 +106,15 @@ __shared__ __attribute__((aligned(256))) unsigned s2s_stats_lds[64];      // [0]
 // [decoder layer 0|1][32-key tile | 16-key step][64 bins of one unit; bin 63: above the pass-0 maximum]
 __shared__ unsigned s2s_hist_lds[2 * 2 * 64];
 #endif
+// static LDS in front of the kernel's dynamic region (the workgroup's budget is their sum: Fused<MODE>::LDS asserts it)
+constexpr int S2S_STATIC_LDS_BYTES = 256
+#ifdef S2S_DIAG
+    + 8 * S2S_DIAG_SLOTS * 8
+#endif
+#ifdef S2S_TILEHIST
+    + 2 * 2 * 64 * 4
+#endif
+    ;
 
 #ifndef S2S_ABL
 #define S2S_ABL 0      // timing-only ablations (tools/ablate.py); results are garbage when non-zero

@@ -139,16 +139,20 @@ __device__ __forceinline__ void split4(const f32x4 t, const float one, h4& hi, h
 // Inside pass j the blocks are rotated by j & 1, so that the 16 lanes of a K store (keys 16 T .. 16 T + 15, four of them in each
 // pass) still spread over eight 8-byte bank slots (2-way, as in the natural order) instead of four.
 // position of key (T, c) = 16 T + c:  64 j + 4 ((T + (j & 1)) & 15) + (c & 3) with j = c >> 2;  key at position p:
+// NATURAL = true (the EXACT kernel instance): position = key.  An online softmax has no use for a sample in pass 0, and in the
+// dealt-out order the six phantom keys (250-255) sit in two passes (tiles 5 and 6) instead of one (tile 7): their masks cost the
+// exact instance 5.3 k cycles per chunk and 7 spilled registers (round 4's review, item 3).
+template <bool NATURAL = false>
 __host__ __device__ constexpr int att32_key_at(const int p) {
-    return 16 * ((((p & 63) >> 2) - ((p >> 6) & 1)) & 15) + 4 * (p >> 6) + (p & 3);
+    return NATURAL ? p : 16 * ((((p & 63) >> 2) - ((p >> 6) & 1)) & 15) + 4 * (p >> 6) + (p & 3);
 }
 // phantom keys (>= TV) -> -inf in the score tile `tile` (a compile-time index; h: the lane half)
-template <int TV>
+template <int TV, bool NATURAL = false>
 __device__ __forceinline__ void att32_mask_tile(f32x16& t, const int tile, const int h) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2);
-        const bool p0 = att32_key_at(32 * tile + row) >= TV, p1 = att32_key_at(32 * tile + row + 4) >= TV;   // lane halves 0 / 1
+        const bool p0 = att32_key_at<NATURAL>(32 * tile + row) >= TV, p1 = att32_key_at<NATURAL>(32 * tile + row + 4) >= TV;   // lane halves 0 / 1
         if (p0 && p1) t[r] = -__builtin_inff();
         else if (p1) t[r] = h ? -__builtin_inff() : t[r];
         else if (p0) t[r] = h ? t[r] : -__builtin_inff();
@@ -370,7 +374,7 @@ __device__ __forceinline__ float sum_h(float v) {
     auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
-template <int TV, bool SAFE, bool LO>
+template <int TV, bool SAFE, bool LO, bool NATURAL = false>
 __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
                                              const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O,
                                              [[maybe_unused]] const int layer = 0) {
@@ -381,8 +385,8 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     O = zero16;
     auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
     auto mask_pass = [&](f32x16 (&t)[2], const int h2) {                  // phantom keys -> -inf (att32_key_at: they sit in tiles 5 and 6)
-        att32_mask_tile<TV>(t[0], 2 * h2, h);
-        att32_mask_tile<TV>(t[1], 2 * h2 + 1, h);
+        att32_mask_tile<TV, NATURAL>(t[0], 2 * h2, h);
+        att32_mask_tile<TV, NATURAL>(t[1], 2 * h2 + 1, h);
     };
     auto pv = [&](const f32x16& t, const h8 (&va)[2]) {                   // O += [V_hi; V_lo; 1] . exp2(t), 16 keys per MFMA
 #pragma unroll
@@ -531,7 +535,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 // softmax_pv32_online: that online softmax with the fast path's operand tricks -- the shift rides in the k-slots of the second
 // score MFMA (no 16-register C operand), a pass's scores are ISSUED AGAIN with the raised shift instead of being lowered by 32
 // subtractions (the matrix pipe has the room), and only accumulator registers 0-8 are rescaled (rows 17-31 of O are zeros).
-template <int TV, bool LO>
+template <int TV, bool LO, bool NATURAL>
 __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
                                                     const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
     constexpr int NT = 8;
@@ -555,8 +559,8 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
         auto score_pass = [&]() {
 #pragma unroll
             for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
-            att32_mask_tile<TV>(sc[0], 2 * h2, h);                        // phantom keys -> -inf (they sit in tiles 5 and 6)
-            att32_mask_tile<TV>(sc[1], 2 * h2 + 1, h);
+            att32_mask_tile<TV, NATURAL>(sc[0], 2 * h2, h);               // phantom keys -> -inf (natural key order: tile 7 only)
+            att32_mask_tile<TV, NATURAL>(sc[1], 2 * h2 + 1, h);
         };
         score_pass();
         float mh = sc[0][0];
@@ -700,7 +704,8 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int T = qt0 + q;
-            const int key = G::ATT32 ? 64 * (c >> 2) + 4 * ((T + ((c >> 2) & 1)) & 15) + (c & 3) : 16 * T + c;      // (ATT32: the position, see att32_key_at)
+            // (ATT32, fast instance: the position of att32_key_at; the EXACT instance keeps the natural order)
+            const int key = G::ATT32 && !EXACT ? 64 * (c >> 2) + 4 * ((T + ((c >> 2) & 1)) & 15) + (c & 3) : 16 * T + c;
             h4 hi, lo;
             split4<LO>(ak[q], one, hi, lo);
             *reinterpret_cast<h4*>(Kl + ((head * 2 + 0) * G::KEYS + key) * 8 + d0) = hi;
@@ -709,7 +714,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
             // (ATT32: this lane's four keys are key block 4 T + g, at block position 16 g + Tr, Tr = (T + (g & 1)) & 15: 16-key step
             //  4 g + (Tr >> 2), block Tr & 3 of it)
             const int Tr = (T + (g & 1)) & 15;
-            const int vcol = G::ATT32 ? 16 * (4 * g + (Tr >> 2)) + 8 * (Tr & 1) + 4 * ((Tr >> 1) & 1)
+            //  natural order (EXACT): key block 4 T + g = 16-key step T, block g of it)
+            const int vcol = G::ATT32 ? (EXACT ? 16 * T + 8 * (g & 1) + 4 * ((g >> 1) & 1)
+                                               : 16 * (4 * g + (Tr >> 2)) + 8 * (Tr & 1) + 4 * ((Tr >> 1) & 1))
                            : G::V128 ? 32 * (T >> 1) + 8 * g + 4 * (T & 1) : 16 * T + 4 * g;   // (position inside the row: see AttnLdsH::VS)
             *reinterpret_cast<h4*>(Vl + vrow * G::VS + vcol) = hi;
             *reinterpret_cast<h4*>(Vl + (vrow + 8) * G::VS + vcol) = lo;
@@ -781,9 +788,9 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     float lsum;
                     if constexpr (EXACT) {                                 // the handle's attention path is "exact" (its own kernel instance)
 #if S2S_ONLINE2 && S2S_ATT32_MSLOT
-                        softmax_pv32_online<TV, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
+                        softmax_pv32_online<TV, LO, true>(kp, kp2, vp, qb1, qb2, one, hl, O);
 #else
-                        softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
+                        softmax_pv32<TV, true, LO, true>(kp, kp2, vp, qb1, qb2, one, hl, O);
 #endif
                         lsum = sum_h(O[8]);                                // row 16 lives in the lower lane half
                     } else {

@@ -12,6 +12,7 @@
 #include "s2s_device_h.h"
 #include "../../include/s2s_hip.h"
 
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -461,7 +462,7 @@ template <int MODE> struct Fused {
     static constexpr int GROUP = DEC_WAVES * FNQ;
     static constexpr bool PF = (MODE == 1);                       // next chunk's slot prefetched into LDS (dec_blocks)
     static constexpr int LDS = (MODE == 0) ? DEC_LDS_F32 : DEC_LDS_H + (S2S_SLOT_FLOATS + S2S_SV_FLOATS + S2S_PROG_INTS + S2S_Z2_FLOATS) * 4;   // + next slot, small vectors, progress counters, 2nd zeros row
-    static_assert(LDS <= 160 * 1024, "LDS per workgroup");
+    static_assert(LDS + S2S_STATIC_LDS_BYTES + 256 <= 160 * 1024, "LDS per workgroup: dynamic + the static arrays in front of it (+ their alignment)");
     static_assert(FMODE == 1 || DEC_WAVES * FrontLdsF32::BYTES <= LDS, "the f32 frontend waves' K/V images share the decoder's LDS");
 };
 #define S2S_MAX_GROUP (2 * DEC_WAVES)
@@ -1271,8 +1272,17 @@ int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int d
     if ((e = hipMalloc(&h->d_diag, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(diag)");
     if ((e = hipMemset(h->d_diag, 0, 8 * 48 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(diag)");
 #endif
-    if (const char* env = getenv("S2S_ATTENTION_PATH")) {          // "fast" / "exact": no calibration launch
-        h->attn_exact = (env[0] == 'e' || env[0] == '1') ? 1 : 0;
+    // S2S_ATTENTION_PATH = fast | exact (any case): that path, no calibration launch; unset, empty or "auto": calibrate;
+    // anything else is refused (a typo must not pin the fast path silently)
+    std::string want;
+    if (const char* env = getenv("S2S_ATTENTION_PATH"))
+        for (const char* c = env; *c; ++c) want += (char)std::tolower((unsigned char)*c);
+    if (want == "fast" || want == "exact") {
+        h->attn_exact = want == "exact" ? 1 : 0;
+    } else if (!want.empty() && want != "auto") {
+        g_create_error = "S2S_ATTENTION_PATH must be fast, exact or auto (got \"" + want + "\")";
+        s2s_destroy(h);
+        return S2S_ERR_ARG;
     } else if (calibrate_attention(h) != S2S_OK) {
         g_create_error = "attention-path calibration launch: " + h->err;
         s2s_destroy(h);

@@ -761,6 +761,14 @@ extern "C" int64_t s2s_length_law(int32_t law, uint32_t seed, double r, int64_t 
 // 594-597, for plain FASTA files): every rank of a sharded run parses the whole reference before its first kernel.
 namespace {
 inline bool fa_blank(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+// Bytes the text-mode line loop treats differently from this byte-level parser: anything >= 0x80 (the loop decodes UTF-8 -- a name
+// keeps its characters, an invalid sequence raises -- and U+0085 / U+00A0 are blanks for str.split) and 0x1c-0x1f (blanks for
+// str.split / str.strip as well).  A file that holds one is left to the line loop.
+inline bool odd_bytes(const uint8_t* data, int64_t n) {
+    unsigned any = 0;
+    for (int64_t k = 0; k < n; ++k) any |= (unsigned)(data[k] >= 0x80) | (unsigned)((uint8_t)(data[k] - 0x1c) < 4);
+    return any != 0;
+}
 }  // namespace
 
 // Number of records ('>' in column 0, as pysam / the line loop of utils.read_fasta take it); -2 when the first non-empty line
@@ -770,13 +778,14 @@ extern "C" int64_t s2s_fasta_count(const uint8_t* data, int64_t n) {
     if (!data || n < 0) return S2S_ERR_ARG;
     int64_t i = 0, recs = 0;
     bool first = true;
+    if (odd_bytes(data, n)) return -3;
     const bool has_cr = n > 0 && std::memchr(data, '\r', (size_t)n) != nullptr;      // (Unix files: one pass, no per-line check)
     while (i < n) {
         const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(data + i, '\n', (size_t)(n - i)));
         int64_t end = nl ? nl - data : n;
         const int64_t next = end + 1;
-        while (end > i && data[end - 1] == '\r') --end;
-        if (has_cr && end > i && std::memchr(data + i, '\r', (size_t)(end - i))) return -3;   // a lone CR inside a line
+        if (end > i && data[end - 1] == '\r') --end;                                 // "\r\n" is ONE line end; a second CR in front of it is a line of its own
+        if (has_cr && end > i && std::memchr(data + i, '\r', (size_t)(end - i))) return -3;   // a lone CR inside (or at the end of) a line
         if (end > i) {
             if (first && data[i] == '@') return -2;
             first = false;
@@ -852,13 +861,14 @@ extern "C" int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_a
     }
     int64_t i = 0, recs = 0, o = 0;
     bool bad = false;
+    if (odd_bytes(data, n)) return -2;
     auto line = [&](int64_t& b, int64_t& e) {                // next line [b, e) without its line end; false at the end of the data
         if (i >= n) return false;
         const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(data + i, '\n', (size_t)(n - i)));
         e = nl ? nl - data : n;
         b = i;
         i = e + 1;
-        while (e > b && data[e - 1] == '\r') --e;
+        if (e > b && data[e - 1] == '\r') --e;                 // one CR belongs to the line end; any other is a line break of its own
         if (e > b && std::memchr(data + b, '\r', (size_t)(e - b))) bad = true;
         return true;
     };
@@ -890,4 +900,88 @@ extern "C" int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_a
     }
     if (!count_only) seq_offs[recs] = o;
     return recs;
+}
+
+// ---- rank-shard merge (`predict --gpus N`, `merge-shards`): the reference writes ONE file (inference.py:65-79), a sharded run
+// writes one per rank, and joining them must not cost more than the ranks' parallel phase did.  Both helpers work on file
+// descriptors; nothing passes through the interpreter or (copy_file_range) through user space.
+#include <cerrno>
+#include <fcntl.h>
+#include <unistd.h>
+
+namespace {
+
+int64_t copy_one(int src, int64_t src_off, int dst, int64_t dst_off, int64_t len, std::vector<uint8_t>& bounce, bool& in_kernel) {
+    while (len > 0) {
+        if (in_kernel) {
+            off_t so = (off_t)src_off, d_o = (off_t)dst_off;
+            const ssize_t r = copy_file_range(src, &so, dst, &d_o, (size_t)std::min<int64_t>(len, 1 << 30), 0);
+            if (r > 0) { src_off += r; dst_off += r; len -= r; continue; }
+            if (r == 0) return -EIO;                                 // source shorter than the caller said
+            if (errno == EINTR) continue;
+            if (errno != EXDEV && errno != ENOSYS && errno != EINVAL && errno != EOPNOTSUPP && errno != EPERM) return -errno;
+            in_kernel = false;                                      // another file system / an old kernel: through a bounce buffer
+        }
+        if (bounce.empty()) bounce.resize(8 << 20);
+        const ssize_t r = pread(src, bounce.data(), (size_t)std::min<int64_t>(len, (int64_t)bounce.size()), (off_t)src_off);
+        if (r == 0) return -EIO;
+        if (r < 0) { if (errno == EINTR) continue; return -errno; }
+        for (ssize_t done = 0; done < r;) {
+            const ssize_t w = pwrite(dst, bounce.data() + done, (size_t)(r - done), (off_t)(dst_off + done));
+            if (w < 0) { if (errno == EINTR) continue; return -errno; }
+            done += w;
+        }
+        src_off += r; dst_off += r; len -= r;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd,
+                                   const int64_t* dst_off, const int64_t* len, int32_t threads) {
+    if (n < 0 || threads < 1 || (n > 0 && (!src_fd || !src_off || !dst_fd || !dst_off || !len))) return S2S_ERR_ARG;
+    // pieces of <= 64 MiB, so that one long range does not leave the other threads idle
+    struct Piece { int src, dst; int64_t so, d_o, len; };
+    std::vector<Piece> pieces;
+    const int64_t cut = 64ll << 20;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (len[i] < 0 || src_off[i] < 0 || dst_off[i] < 0) return S2S_ERR_ARG;
+        for (int64_t o = 0; o < len[i]; o += cut)
+            pieces.push_back({src_fd[i], dst_fd[i], src_off[i] + o, dst_off[i] + o, std::min(cut, len[i] - o)});
+        total += len[i];
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int64_t> err{0};
+    auto work = [&] {
+        std::vector<uint8_t> bounce;
+        bool in_kernel = true;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= pieces.size() || err.load()) return;
+            const Piece& p = pieces[i];
+            const int64_t r = copy_one(p.src, p.so, p.dst, p.d_o, p.len, bounce, in_kernel);
+            if (r < 0) err = r;
+        }
+    };
+    const int workers = (int)std::min<size_t>((size_t)threads, std::max<size_t>(pieces.size(), 1));
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; ++w) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    return err.load() < 0 ? err.load() : total;
+}
+
+extern "C" int64_t s2s_blow5_scan(int32_t fd, int64_t begin, int64_t end) {
+    if (fd < 0 || begin < 0 || end < begin) return S2S_ERR_ARG;
+    int64_t pos = begin, n = 0;
+    while (pos < end) {
+        uint64_t size;
+        if (end - pos < 8 || pread(fd, &size, 8, (off_t)pos) != 8) return -2;
+        if (size > (uint64_t)(end - pos - 8)) return -2;                // a record runs past the end-of-file marker: truncated shard
+        pos += 8 + (int64_t)size;
+        ++n;
+    }
+    return n;
 }

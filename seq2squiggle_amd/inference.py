@@ -17,6 +17,9 @@ from .utils import get_profile, get_reads, update_config, update_profile
 logger = logging.getLogger("seq2squiggle")
 
 
+REDO_WARN_RATE = 0.08        # the threshold of s2s_create's calibration (csrc/s2s_hip.hip: calibrate_attention)
+
+
 def get_writer(out: str, profile: object, ideal_mode: bool, export_every_n_samples: int, profile_name: str,
                preserve_read_ids: bool) -> tuple:
     """Writer by output extension (inference.py:30-82): deletes an existing file, creates the directory."""
@@ -348,9 +351,13 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
                   duration_sampling: bool, distr: str, predict_batch_size: int, export_every_n_samples: int,
                   sample_rate: int, bps: int, digitisation: int, range_val: float, offset_mean: float, offset_std: float,
                   median_before_mean: float, median_before_std: float, min_noise: float, min_duration: float,
-                  min_read_len: int, preserve_read_ids: bool, seed: int, mode: str = "f16x3", streaming: bool = True):
-    """Same 30 parameters as the reference (inference.py:270-301) plus `mode` (decoder arithmetic) and `streaming`
-    (True: run_streaming; False: the reference's predict_step / export_and_clear_results flow, batch by batch)."""
+                  min_read_len: int, preserve_read_ids: bool, seed: int, mode: str = "f16x3", streaming: bool = True,
+                  attention_path: str = "auto"):
+    """Same 30 parameters as the reference (inference.py:270-301) plus `mode` (decoder arithmetic), `streaming`
+    (True: run_streaming; False: the reference's predict_step / export_and_clear_results flow, batch by batch) and
+    `attention_path` ("auto": the engine's calibration decides; "fast" / "exact": Engine.attention_path is set to it)."""
+    if attention_path not in ("auto", "fast", "exact"):
+        raise ValueError("attention_path must be 'auto', 'fast' or 'exact'")
     profile_dict = get_profile(profile)
     profile_dict = update_profile(profile_dict, sample_rate=sample_rate, bps=bps, digitisation=digitisation, range=range_val,
                                   offset_mean=offset_mean, offset_std=offset_std, median_before_mean=median_before_mean,
@@ -420,6 +427,8 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     if first_read:
         writer.start_at(first_read)            # read ids / read_number / record draws continue the single-process run
     load_model = loading.result()
+    if attention_path != "auto":
+        load_model.engine.attention_path = attention_path
     load_model.chunks_done = int(first_chunk)  # global chunk index of this rank's first chunk: keys the device RNG counters
     load_model.first_global_chunk = int(first_chunk)
     check_model(load_model, config)
@@ -437,12 +446,19 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
         load_model.on_predict_epoch_end()
     torch.cuda.synchronize(load_model.device)
     logger.info(f"Predicted {n_chunks} chunks ({n_chunks * 250} padded samples).")
-    if logger.isEnabledFor(logging.DEBUG):     # how THESE weights behaved on the kernel (s2s_stats_read; the read resets the counters)
-        eng = load_model.engine
-        st = eng.stats()
-        logger.debug(f"attention path {eng.attention_path} (calibration launch: {100 * eng.calibration_redo_rate:.2f} % of the heads redone); "
-                     f"this run: {100 * st['redo_rate']:.3f} % redone, {st['in_kernel_clock_ghz'] or 0:.2f} GHz in the kernel, "
-                     f"{st['cycles_per_chunk_and_cu'] or 0:.0f} cycles per chunk and CU")
+    # how THESE weights behaved on THIS input (s2s_stats_read; the read resets the counters): the redo share of the fast softmax
+    # path depends on the reads as well as on the checkpoint, and the calibration launch only saw 512 pseudo-random chunks
+    eng = load_model.engine
+    st = eng.stats()
+    load_model.run_stats = dict(st, attention_path=eng.attention_path, calibration_redo_rate=eng.calibration_redo_rate)
+    logger.debug(f"attention path {eng.attention_path} (calibration launch: {100 * eng.calibration_redo_rate:.2f} % of the heads redone); "
+                 f"this run: {100 * st['redo_rate']:.3f} % redone, {st['in_kernel_clock_ghz'] or 0:.2f} GHz in the kernel, "
+                 f"{st['cycles_per_chunk_and_cu'] or 0:.0f} cycles per chunk and CU")
+    if eng.attention_path == "fast" and st["redo_rate"] > REDO_WARN_RATE:
+        logger.warning(f"{100 * st['redo_rate']:.1f} % of the attention heads of this run overflowed the fast softmax path and were redone "
+                       f"(the checkpoint's calibration launch saw {100 * max(eng.calibration_redo_rate, 0):.1f} %; above "
+                       f"{100 * REDO_WARN_RATE:.0f} % the exact path is faster). The output is the same either way; "
+                       f"for this kind of input run with --attention-path exact.")
     shard = rank_output_path(str(out), rank, world)
     if world > 1 and not os.path.exists(shard) and hasattr(writer, "write_records"):
         # a rank without reads (more ranks than reads) still leaves its -- empty -- shard, so that the rank files always merge

@@ -1,0 +1,202 @@
+"""Joining the per-rank files of a sharded run (`predict --gpus N`, parallel.rank_output_path) into the ONE file the reference
+leaves (inference.py:65-79; signal_io.py:167-171, 268-282) without re-reading a record in the interpreter.
+
+A shard's payload -- the BLOW5 record section, the lines of a SLOW5 file, the buffers of a POD5 signal table -- is a handful of
+byte ranges whose place in the merged file follows from prefix sums, so the merge is: lay out, then copy every range with
+copy_file_range from several threads (s2s_copy_ranges in libs2s_hip.so: in the kernel, no user-space buffer), then write the few
+KB that are new (BLOW5: the end marker; POD5: batch metadata, the reads table, the footers -- pod5_io.merge_pod5).
+`take_first=True` turns the first shard INTO the output file (its payload is already where it belongs), so only the other
+shards' bytes move; the shard files are consumed then."""
+import os
+import struct
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+BLOW5_EOF = b"5WOLB"
+
+
+def merge_threads() -> int:
+    """Copy threads of a merge: the CPU share of this process (signal_io.cpu_share), S2S_MERGE_THREADS overrides."""
+    from .signal_io import cpu_share
+    return max(1, int(os.environ.get("S2S_MERGE_THREADS", "0")) or min(32, cpu_share()))
+
+
+def copy_ranges(jobs: Sequence[Tuple[int, int, int, int, int]], threads: int = None) -> int:
+    """jobs: (src_fd, src_offset, dst_fd, dst_offset, length).  Ranges of one file must not overlap.  -> bytes copied."""
+    jobs = [j for j in jobs if j[4] > 0]
+    if not jobs:
+        return 0
+    threads = threads or merge_threads()
+    a = np.array(jobs, dtype=np.int64)
+    try:
+        from ._lib import lib
+        fn = getattr(lib(), "s2s_copy_ranges", None)
+    except (RuntimeError, OSError):
+        fn = None                                  # `merge-shards` on a host without the built library: the same calls from Python threads
+    if fn is not None:
+        src, so, dst, do, ln = (np.ascontiguousarray(a[:, i], dtype=t) for i, t in
+                                enumerate((np.int32, np.int64, np.int32, np.int64, np.int64)))
+        got = fn(len(jobs), src.ctypes.data, so.ctypes.data, dst.ctypes.data, do.ctypes.data, ln.ctypes.data, int(threads))
+        if got < 0:
+            raise OSError(f"s2s_copy_ranges failed ({got}: a bad argument, or -errno of the failing copy_file_range / pread / pwrite)")
+        return int(got)
+    pieces = [(s, so + o, d, do + o, min(64 << 20, ln - o)) for s, so, d, do, ln in jobs for o in range(0, ln, 64 << 20)]
+
+    def one(p):
+        s, so, d, do, ln = p
+        while ln > 0:
+            try:
+                r = os.copy_file_range(s, d, ln, so, do)
+            except OSError:
+                r = os.pwrite(d, os.pread(s, min(ln, 8 << 20), so), do)
+            if r <= 0:
+                raise OSError("short copy while merging shard files")
+            so, do, ln = so + r, do + r, ln - r
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(one, pieces))
+    return int(a[:, 4].sum())
+
+
+class _Files:
+    """Open descriptors of the shard files (+ the output), closed together."""
+
+    def __init__(self):
+        self.fds: List[int] = []
+
+    def open(self, path: str, flags: int = os.O_RDONLY, mode: int = 0o644) -> int:
+        fd = os.open(path, flags, mode)
+        self.fds.append(fd)
+        return fd
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        for fd in self.fds:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+
+
+def _blow5_layout(fd: int, path: str):
+    """-> (64-byte file header, header text bytes, begin, end of the record section) of one BLOW5 shard."""
+    size = os.fstat(fd).st_size
+    head = os.pread(fd, 68, 0)
+    if len(head) < 68 or head[:6] != b"BLOW5\x01":
+        raise ValueError(f"{path}: not a BLOW5 file")
+    hlen = struct.unpack_from("<I", head, 64)[0]
+    text = os.pread(fd, hlen, 68)
+    end = size - len(BLOW5_EOF)
+    if end < 68 + hlen or os.pread(fd, len(BLOW5_EOF), end) != BLOW5_EOF:
+        raise ValueError(f"{path}: no end-of-file marker (truncated shard?)")
+    return head[:64], text, 68 + hlen, end
+
+
+def _scan_blow5(fd: int, begin: int, end: int, path: str) -> int:
+    """Number of records between begin and end (size prefixes only; s2s_blow5_scan, or the same walk with os.pread)."""
+    try:
+        from ._lib import lib
+        fn = getattr(lib(), "s2s_blow5_scan", None)
+    except (RuntimeError, OSError):
+        fn = None
+    if fn is not None:
+        n = int(fn(fd, begin, end))
+    else:
+        n, pos = 0, begin
+        while pos < end:
+            raw = os.pread(fd, 8, pos)
+            if len(raw) < 8 or struct.unpack("<Q", raw)[0] > end - pos - 8:
+                n = -2
+                break
+            pos += 8 + struct.unpack("<Q", raw)[0]
+            n += 1
+    if n < 0:
+        raise ValueError(f"{path}: truncated record (the size prefixes do not end at the end-of-file marker)")
+    return n
+
+
+def merge_blow5(paths: Sequence[str], out: str, threads: int = None, take_first: bool = False) -> Tuple[int, dict]:
+    """BLOW5 shards with identical headers -> `out`: header of the first, every shard's record section at its prefix-sum offset,
+    one end-of-file marker.  Nothing is decompressed or parsed beyond the u64 size prefixes (counted for the return value and
+    as the truncation check).  -> (records, {"bytes_copied", "seconds"})."""
+    t0 = time.perf_counter()
+    threads = threads or merge_threads()
+    same = lambda text: [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]   # the wall clock may differ
+    with _Files() as files:
+        fds = [files.open(p_) for p_ in paths]
+        lay = [_blow5_layout(fd, p_) for fd, p_ in zip(fds, paths)]
+        for p_, (head, text, _, _) in zip(paths[1:], lay[1:]):
+            if head != lay[0][0] or same(text) != same(lay[0][1]):
+                raise ValueError(f"{p_}: header differs from {paths[0]} (another profile, compression or run?)")
+        with ThreadPoolExecutor(max_workers=min(threads, len(paths))) as ex:
+            counts = list(ex.map(lambda i: _scan_blow5(fds[i], lay[i][2], lay[i][3], paths[i]), range(len(paths))))
+        sizes = [end - begin for _, _, begin, end in lay]
+        at = np.concatenate([[lay[0][2]], lay[0][2] + np.cumsum(sizes)]).astype(np.int64)
+        if take_first:
+            os.replace(paths[0], out)
+            dst = files.open(out, os.O_RDWR)
+            first = 1
+        else:
+            dst = files.open(out, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+            os.pwrite(dst, lay[0][0] + struct.pack("<I", len(lay[0][1])) + lay[0][1], 0)
+            first = 0
+        os.ftruncate(dst, int(at[-1]) + len(BLOW5_EOF))
+        copied = copy_ranges([(fds[i], lay[i][2], dst, int(at[i]), sizes[i]) for i in range(first, len(paths))], threads)
+        os.pwrite(dst, BLOW5_EOF, int(at[-1]))
+    return int(sum(counts)), {"bytes_copied": copied, "seconds": time.perf_counter() - t0}
+
+
+def _slow5_header_end(fd: int, path: str) -> int:
+    """Byte offset of the first record line (the first line that starts with neither '#' nor '@')."""
+    size, pos, carry = os.fstat(fd).st_size, 0, b""
+    while pos < size:
+        blk = os.pread(fd, 1 << 16, pos)
+        data = carry + blk
+        start = pos - len(carry)
+        o = 0
+        while True:
+            if o >= len(data):
+                break
+            if data[o:o + 1] not in (b"#", b"@"):
+                return start + o
+            nl = data.find(b"\n", o)
+            if nl < 0:
+                break
+            o = nl + 1
+        carry, pos = data[o:], pos + len(blk)
+    return size                                   # a header without records
+
+
+def merge_slow5(paths: Sequence[str], out: str, threads: int = None) -> Tuple[int, dict]:
+    """SLOW5 (ASCII) shards: header lines of the first, the record lines of all -- raw ranges; the records are counted as
+    line ends while the ranges are in flight."""
+    t0 = time.perf_counter()
+    with _Files() as files:
+        fds = [files.open(p_) for p_ in paths]
+        begins = [_slow5_header_end(fd, p_) for fd, p_ in zip(fds, paths)]
+        ends = [os.fstat(fd).st_size for fd in fds]
+        for p_, fd, b, e in zip(paths, fds, begins, ends):
+            if e > b and os.pread(fd, 1, e - 1) != b"\n":
+                raise ValueError(f"{p_}: the last record has no line end (truncated shard?)")
+        header = os.pread(fds[0], begins[0], 0)
+        at = np.concatenate([[len(header)], len(header) + np.cumsum([e - b for b, e in zip(begins, ends)])]).astype(np.int64)
+        dst = files.open(out, os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        os.pwrite(dst, header, 0)
+        os.ftruncate(dst, int(at[-1]))
+
+        def lines(i):
+            n, pos = 0, begins[i]
+            while pos < ends[i]:
+                blk = os.pread(fds[i], min(16 << 20, ends[i] - pos), pos)
+                n += blk.count(b"\n")
+                pos += len(blk)
+            return n
+        with ThreadPoolExecutor(max_workers=max(1, min(threads or merge_threads(), len(paths)))) as ex:
+            counting = ex.map(lines, range(len(paths)))
+            copied = copy_ranges([(fds[i], begins[i], dst, int(at[i]), ends[i] - begins[i]) for i in range(len(paths))], threads)
+            n = sum(counting)
+    return int(n), {"bytes_copied": copied, "seconds": time.perf_counter() - t0}

@@ -15,6 +15,7 @@ Layout:  signature | marker | signal table | pad8 | marker | run-info table | pa
 """
 import datetime as _dt
 import io
+from concurrent.futures import ThreadPoolExecutor
 import struct
 import uuid
 from typing import Dict, List, Sequence
@@ -213,7 +214,29 @@ def _run_info_table(pa, meta, run_infos: List[dict]) -> bytes:
     return _ipc_bytes(pa, schema, [pa.record_batch(cols, schema=schema)])
 
 
-def _reads_table(pa, meta, reads, rows_of, run_ids: List[str], pore_types: List[str]) -> bytes:
+READ_COLUMNS = (("read_number", "uint32"), ("start", "uint64"), ("median_before", "float32"), ("num_samples", "uint64"),
+                ("channel", "uint16"), ("well", "uint8"), ("calibration_offset", "float32"), ("calibration_scale", "float32"),
+                ("end_reason_forced", "bool"))
+
+
+def _read_columns(reads, rows_of, run_ids: List[str], pore_types: List[str]) -> dict:
+    """The per-read dicts of Pod5FileWriter as the columns _reads_table writes (numpy arrays, n reads)."""
+    src = {"start": "start_sample"}
+    cols = {name: np.array([r[src.get(name, name)] for r in reads], dtype=dt) for name, dt in READ_COLUMNS}
+    cols["read_id"] = np.frombuffer(b"".join(r["read_id"].bytes for r in reads), dtype=np.uint8).reshape(-1, 16)
+    cols["signal_offsets"] = np.concatenate([[0], np.cumsum([len(x) for x in rows_of])]).astype(np.int32)
+    cols["signal_rows"] = np.fromiter((i for x in rows_of for i in x), dtype=np.uint64, count=int(cols["signal_offsets"][-1]))
+    cols["pore_type"] = np.array([pore_types.index(r["pore_type"]) for r in reads], dtype=np.int16)
+    cols["end_reason"] = np.array([END_REASONS.index(r["end_reason"]) for r in reads], dtype=np.int16)
+    cols["run_info"] = np.array([run_ids.index(r["run_info"]["acquisition_id"]) for r in reads], dtype=np.int16)
+    return cols
+
+
+def _reads_table(pa, meta, cols: dict, run_ids: List[str], pore_types: List[str]) -> bytes:
+    """The reads table (spec v3) from columns: read_id [n][16] u8, signal_offsets [n+1] i32 + signal_rows (the signal-table rows of
+    every read, back to back), READ_COLUMNS, and the dictionary indices pore_type / end_reason / run_info (int16).  Every batch is
+    assembled from slices of these arrays: no per-read Python object (the writer and merge_pod5 both come through here, so their
+    files agree byte for byte)."""
     f32, d = pa.float32(), lambda: pa.dictionary(pa.int16(), pa.utf8())
     fields = [_uuid_field(pa), pa.field("signal", pa.list_(pa.uint64())), pa.field("read_number", pa.uint32()),
               pa.field("start", pa.uint64()), pa.field("median_before", f32), pa.field("num_minknow_events", pa.uint64()),
@@ -225,27 +248,49 @@ def _reads_table(pa, meta, reads, rows_of, run_ids: List[str], pore_types: List[
               pa.field("end_reason", d()), pa.field("end_reason_forced", pa.bool_()), pa.field("run_info", d())]
     schema = pa.schema(fields, metadata=meta)
     pore_dict, end_dict, run_dict = pa.array(pore_types, pa.utf8()), pa.array(END_REASONS, pa.utf8()), pa.array(run_ids, pa.utf8())
-    nan = float("nan")
+    n_reads = len(cols["read_number"])
+    ids, sig_offs, sig_rows = np.ascontiguousarray(cols["read_id"], dtype=np.uint8), cols["signal_offsets"], cols["signal_rows"]
     batches = []
-    for lo in range(0, len(reads), READ_BATCH_ROWS):
-        part, rows = reads[lo: lo + READ_BATCH_ROWS], rows_of[lo: lo + READ_BATCH_ROWS]
-        n = len(part)
-        col = lambda key, t: pa.array([r[key] for r in part], t)
-        const = lambda v, t: pa.array([v] * n, t)
-        dic = lambda idx, dictionary: pa.DictionaryArray.from_arrays(pa.array(idx, pa.int16()), dictionary)
+    for lo in range(0, n_reads, READ_BATCH_ROWS):
+        hi = min(lo + READ_BATCH_ROWS, n_reads)
+        n = hi - lo
+        col = lambda key, t: pa.array(np.ascontiguousarray(cols[key][lo:hi]), t)
+        const = lambda v, dt, t: pa.array(np.full(n, v, dtype=dt), t)
+        dic = lambda key, dictionary: pa.DictionaryArray.from_arrays(pa.array(np.ascontiguousarray(cols[key][lo:hi]), pa.int16()), dictionary)
+        rows = pa.ListArray.from_arrays(pa.array((sig_offs[lo:hi + 1] - sig_offs[lo]).astype(np.int32), pa.int32()),
+                                        pa.array(np.ascontiguousarray(sig_rows[sig_offs[lo]:sig_offs[hi]], dtype=np.uint64), pa.uint64()))
         batches.append(pa.record_batch([
-            pa.array([r["read_id"].bytes for r in part], pa.binary(16)), pa.array(rows, pa.list_(pa.uint64())),
-            col("read_number", pa.uint32()), col("start_sample", pa.uint64()), col("median_before", f32),
-            const(0, pa.uint64()), const(nan, f32), const(nan, f32), const(nan, f32), const(nan, f32),
-            const(0, pa.uint32()), const(0.0, f32), col("num_samples", pa.uint64()),
-            col("channel", pa.uint16()), col("well", pa.uint8()), dic([pore_types.index(r["pore_type"]) for r in part], pore_dict),
+            pa.FixedSizeBinaryArray.from_buffers(pa.binary(16), n, [None, pa.py_buffer(ids[lo:hi].tobytes())]), rows,
+            col("read_number", pa.uint32()), col("start", pa.uint64()), col("median_before", f32),
+            const(0, np.uint64, pa.uint64()), const(np.nan, np.float32, f32), const(np.nan, np.float32, f32),
+            const(np.nan, np.float32, f32), const(np.nan, np.float32, f32),
+            const(0, np.uint32, pa.uint32()), const(0.0, np.float32, f32), col("num_samples", pa.uint64()),
+            col("channel", pa.uint16()), col("well", pa.uint8()), dic("pore_type", pore_dict),
             col("calibration_offset", f32), col("calibration_scale", f32),
-            dic([END_REASONS.index(r["end_reason"]) for r in part], end_dict), col("end_reason_forced", pa.bool_()),
-            dic([run_ids.index(r["run_info"]["acquisition_id"]) for r in part], run_dict)], schema=schema))
+            dic("end_reason", end_dict), col("end_reason_forced", pa.bool_()), dic("run_info", run_dict)], schema=schema))
     return _ipc_bytes(pa, schema, batches)
 
 
 # ------------------------------------------------------------------------------------------------ file
+def _write_tail(f, pa, meta, marker: bytes, file_identifier, sig_start: int, run_infos: List[dict], cols: dict,
+                run_ids: List[str], pore_types: List[str]) -> None:
+    """Everything behind the signal table (f stands at its end): pad + marker, the run-info and reads tables, the footer."""
+    entries = []
+
+    def end_embedded(start, content_type):
+        n = f.tell() - start
+        entries.append((start, n, content_type))
+        f.write(bytes(-n % 8) + marker)
+    end_embedded(sig_start, CT_SIGNAL)
+    for ct, data in ((CT_RUN_INFO, _run_info_table(pa, meta, run_infos)),
+                     (CT_READS, _reads_table(pa, meta, cols, run_ids, pore_types))):
+        start = f.tell()
+        f.write(data)
+        end_embedded(start, ct)
+    fb = build_footer(str(file_identifier), SOFTWARE, POD5_VERSION, entries)
+    f.write(FOOTER_MAGIC + fb + struct.pack("<q", len(fb)) + marker + SIGNATURE)
+
+
 class Pod5FileWriter:
     """Streaming writer: the signal table is the first embedded file and grows batch by batch while reads arrive; the
     per-read rows (about 100 B each) are kept until close(), which writes the run-info and reads tables and the footer.
@@ -270,7 +315,6 @@ class Pod5FileWriter:
                      "MINKNOW:pod5_version": POD5_VERSION}
         self.f = open(path, "xb")                     # like pod5.Writer: refuses to overwrite
         self.f.write(SIGNATURE + self.marker)
-        self.entries = []
         self._sig_start = self.f.tell()
         self._sig_schema = _signal_schema(pa, self.meta, self.vbz)
         self._sig_writer = pa.ipc.new_file(_SubFile(self.f), self._sig_schema)
@@ -309,11 +353,6 @@ class Pod5FileWriter:
             self._sig_writer.write_batch(_signal_batch(self.pa, self._sig_schema, self._pending[:SIGNAL_BATCH_ROWS], self.vbz))
             del self._pending[:SIGNAL_BATCH_ROWS]
 
-    def _end_embedded(self, start, content_type):
-        n = self.f.tell() - start
-        self.entries.append((start, n, content_type))
-        self.f.write(bytes(-n % 8) + self.marker)
-
     def close(self) -> None:
         if self.closed:
             return
@@ -323,15 +362,10 @@ class Pod5FileWriter:
             self._sig_writer.write_batch(_signal_batch(pa, self._sig_schema, self._pending, self.vbz))
             self._pending = []
         self._sig_writer.close()
-        self._end_embedded(self._sig_start, CT_SIGNAL)
         pore_types = sorted({r["pore_type"] for r in self._reads})
-        for ct, data in ((CT_RUN_INFO, _run_info_table(pa, self.meta, self._run_infos)),
-                         (CT_READS, _reads_table(pa, self.meta, self._reads, self._rows_of, self._run_ids, pore_types))):
-            start = self.f.tell()
-            self.f.write(data)
-            self._end_embedded(start, ct)
-        fb = build_footer(str(self.file_identifier), SOFTWARE, POD5_VERSION, self.entries)
-        self.f.write(FOOTER_MAGIC + fb + struct.pack("<q", len(fb)) + self.marker + SIGNATURE)
+        cols = _read_columns(self._reads, self._rows_of, self._run_ids, pore_types)
+        _write_tail(self.f, pa, self.meta, self.marker, self.file_identifier, self._sig_start, self._run_infos, cols,
+                    self._run_ids, pore_types)
         self.f.close()
 
     def __enter__(self):
@@ -459,25 +493,355 @@ def iter_pod5(path: str, decode: bool = True):
             yield dict(r, read_id=uuid.UUID(bytes=r["read_id"])), raw
 
 
-def merge_pod5(paths: Sequence[str], out: str) -> int:
-    """Concatenate POD5 files written by this package (the out.rankN.pod5 shards of a multi-process run) into one file: reads in
-    the order given, their VBZ signal rows copied as stored (nothing is decoded), run-info records united by acquisition id, one
-    reads table.  Streams shard by shard; memory = one signal batch + 100 B per read.  -> number of reads."""
-    n = 0
-    with Pod5FileWriter(out, signal_compression="vbz") as w:
-        for p_ in paths:
-            batch = []
-            for r, rows in iter_pod5(p_, decode=False):
-                ri = dict(r["run_info_record"])
-                ri["context_tags"], ri["tracking_id"] = dict(ri["context_tags"]), dict(ri["tracking_id"])
-                batch.append(dict(read_id=r["read_id"], vbz_rows=rows, num_samples=r["num_samples"], read_number=r["read_number"],
-                                  start_sample=r["start"], median_before=r["median_before"], channel=r["channel"], well=r["well"],
-                                  pore_type=r["pore_type"], calibration_offset=r["calibration_offset"],
-                                  calibration_scale=r["calibration_scale"], end_reason=r["end_reason"],
-                                  end_reason_forced=r["end_reason_forced"], run_info=ri))
-                n += 1
-                if len(batch) >= 256:
-                    w.add_reads(batch)
-                    batch = []
-            w.add_reads(batch)
-    return n
+# ------------------------------------------------------------------------------------------------ shard merge
+_BLOCK = np.dtype([("offset", "<i8"), ("meta", "<i4"), ("pad", "<i4"), ("body", "<i8")])   # Arrow File.fbs: struct Block
+
+
+def _fb_fields(fb, table: int) -> List[int]:
+    """Absolute positions of a flatbuffer table's fields (0 = absent)."""
+    vt = table - struct.unpack_from("<i", fb, table)[0]
+    vsize = struct.unpack_from("<H", fb, vt)[0]
+    return [table + o if o else 0 for o in struct.unpack_from("<%dH" % ((vsize - 4) // 2), fb, vt + 4)]
+
+
+def _fb_follow(fb, pos: int) -> int:
+    return pos + struct.unpack_from("<I", fb, pos)[0]
+
+
+def _arrow_blocks(buf, start: int, length: int):
+    """The record-batch blocks of the Arrow IPC file at buf[start : start+length] -> (structured array of _BLOCK: offsets from
+    `start`; position of the blocks inside the footer flatbuffer; position of the footer flatbuffer from `start`)."""
+    end = start + length
+    if bytes(buf[start:start + 6]) != b"ARROW1" or bytes(buf[end - 6:end]) != b"ARROW1":
+        raise ValueError("embedded table is not an Arrow IPC file")
+    flen = struct.unpack_from("<i", buf, end - 10)[0]
+    fpos = end - 10 - flen
+    fb = bytes(buf[fpos:fpos + flen])
+    f = _fb_fields(fb, struct.unpack_from("<I", fb, 0)[0])
+    if len(f) < 4 or not f[3]:
+        return np.zeros(0, _BLOCK), 0, fpos - start
+    vec = _fb_follow(fb, f[3])
+    n = struct.unpack_from("<I", fb, vec)[0]
+    return np.frombuffer(fb, _BLOCK, n, vec + 4), vec + 4, fpos - start
+
+
+def _batch_message(buf, pos: int) -> dict:
+    """Where the numbers of one encapsulated RecordBatch message sit (Message.fbs): positions are relative to `pos`, the
+    message's continuation marker.  nodes / buffers: (position of the first struct, count); every struct is two int64."""
+    cont, mlen = struct.unpack_from("<Ii", buf, pos)
+    if cont != 0xFFFFFFFF:
+        raise ValueError("Arrow message without continuation marker (a pre-0.15 stream?)")
+    fb = bytes(buf[pos + 8: pos + 8 + mlen])
+    f = _fb_fields(fb, struct.unpack_from("<I", fb, 0)[0])
+    if fb[f[1]] != 3:
+        raise ValueError("not a RecordBatch message")
+    h = _fb_fields(fb, _fb_follow(fb, f[2]))
+    nodes, buffers = _fb_follow(fb, h[1]), _fb_follow(fb, h[2])
+    return {"meta": 8 + mlen, "body_len": 8 + f[3], "length": 8 + h[0],
+            "nodes": (8 + nodes + 4, struct.unpack_from("<I", fb, nodes)[0]),
+            "buffers": (8 + buffers + 4, struct.unpack_from("<I", fb, buffers)[0]),
+            "compressed": len(h) > 3 and bool(h[3])}
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+class _Shard:
+    """One shard file, memory-mapped: container checks as in iter_pod5, then the byte position of every signal-table row."""
+
+    def __init__(self, path: str):
+        import mmap
+        import os
+        self.path = path
+        self.fd = os.open(path, os.O_RDONLY)
+        size = os.fstat(self.fd).st_size
+        self.buf = buf = mmap.mmap(self.fd, 0, access=mmap.ACCESS_READ)
+        if buf[:8] != SIGNATURE or buf[size - 8:size] != SIGNATURE:
+            raise ValueError(f"{path}: not a POD5 file: bad signature")
+        self.marker = buf[8:24]
+        if buf[size - 24:size - 8] != self.marker:
+            raise ValueError(f"{path}: section markers differ")
+        flen = struct.unpack_from("<q", buf, size - 32)[0]
+        fstart = size - 32 - flen
+        if buf[fstart - 8:fstart] != FOOTER_MAGIC:
+            raise ValueError(f"{path}: footer magic not found")
+        self.footer = parse_footer(buf[fstart:fstart + flen])
+        self.at = {}
+        for e in self.footer["contents"]:
+            end = e["offset"] + e["length"]
+            if buf[end + (-e["length"] % 8): end + (-e["length"] % 8) + 16] != self.marker:
+                raise ValueError(f"{path}: embedded file is not followed by the section marker")
+            self.at[e["content_type"]] = (e["offset"], e["length"])
+
+    def table(self, content_type):
+        pa = _pa()
+        o, n = self.at[content_type]
+        return pa.ipc.open_file(pa.BufferReader(pa.py_buffer(self.buf).slice(o, n)))
+
+    def signal_rows(self, vbz: bool):
+        """-> (ids [n][16] u8, samples [n] u32, lens [n] i64 in bytes (VBZ) or int16 samples (uncompressed), pos [n] i64: file offset
+        of each row's data, offset of the first record batch in the file, its schema)."""
+        buf = self.buf
+        start, length = self.at[CT_SIGNAL]
+        blocks, _, _ = _arrow_blocks(buf, start, length)
+        ids, counts, lens, pos = [], [], [], []
+        width = 1 if vbz else 2
+        for b in blocks:
+            at = start + int(b["offset"])
+            m = _batch_message(buf, at)
+            if m["compressed"]:
+                raise ValueError(f"{self.path}: Arrow buffer compression in the signal table is not something this writer produces")
+            k = struct.unpack_from("<q", buf, at + m["length"])[0]
+            bufs = np.frombuffer(buf, "<i8", 2 * m["buffers"][1], at + m["buffers"][0]).reshape(-1, 2)
+            if len(bufs) != (7 if vbz else 8):
+                raise ValueError(f"{self.path}: unexpected signal-table layout ({len(bufs)} buffers)")
+            body = at + int(b["meta"])
+            ids.append(np.frombuffer(buf, np.uint8, 16 * k, body + int(bufs[1, 0])).reshape(k, 16))
+            offs = np.frombuffer(buf, "<i8", k + 1, body + int(bufs[3, 0]))
+            lens.append(np.diff(offs))
+            pos.append(body + int(bufs[4 if vbz else 5, 0]) + width * offs[:-1])
+            counts.append(np.frombuffer(buf, "<u4", k, body + int(bufs[-1, 0])))
+        cat = lambda xs, dt, shape: np.concatenate(xs) if xs else np.zeros(shape, dt)
+        return (cat(ids, np.uint8, (0, 16)), cat(counts, np.uint32, 0), cat(lens, np.int64, 0), cat(pos, np.int64, 0))
+
+    def close(self):
+        import os
+        self.buf = None        # (views handed out keep the map alive until they go)
+        os.close(self.fd)
+
+
+def _signal_template(pa, schema, vbz: bool, k: int):
+    """One k-row signal batch as pyarrow writes it, with one byte (one sample) of data per row: -> (file head = magic + schema
+    message, message bytes, _batch_message of it, its buffer table, tail = end-of-stream marker + footer + length + magic with ONE
+    block)."""
+    rows = [(bytes(16), None if vbz else np.zeros(1, np.int16), b"\0" if vbz else None, 1) for _ in range(k)]
+    data = _ipc_bytes(pa, schema, [_signal_batch(pa, schema, rows, vbz)])
+    blocks, _, fpos = _arrow_blocks(data, 0, len(data))
+    at, end = int(blocks[0]["offset"]), int(blocks[0]["offset"] + blocks[0]["meta"] + blocks[0]["body"])
+    msg = data[at:end]
+    m = _batch_message(msg, 0)
+    return data[:at], msg, m, np.frombuffer(msg, "<i8", 2 * m["buffers"][1], m["buffers"][0]).reshape(-1, 2).copy()
+
+
+def _arrow_tail(pa, schema, blocks: np.ndarray) -> bytes:
+    """End-of-stream marker + file footer + footer length + magic of an Arrow IPC file of `schema` whose record batches sit at
+    `blocks`: pyarrow writes the footer (for that many empty batches), the Block structs are then overwritten in place."""
+    import io
+    sink = io.BytesIO()
+    empty = pa.RecordBatch.from_arrays([pa.array([], f.type) for f in schema], schema=schema)
+    with pa.ipc.new_file(sink, schema) as w:
+        for _ in range(len(blocks)):
+            w.write_batch(empty)
+    data = bytearray(sink.getvalue())
+    mine, at, fpos = _arrow_blocks(data, 0, len(data))
+    assert len(mine) == len(blocks)
+    tail_from = int(mine[-1]["offset"] + mine[-1]["meta"] + mine[-1]["body"]) if len(mine) else fpos - 8
+    if len(blocks):
+        np.frombuffer(data, _BLOCK, len(blocks), fpos + at)[:] = blocks
+    return bytes(data[tail_from:])
+
+
+def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: bool = False, file_identifier=None,
+               section_marker: bytes = None) -> int:
+    """POD5 shards written by this package (the out.rankN.pod5 files of a multi-process run) -> one file with the reads in the order
+    given.  The signal table is re-batched WITHOUT touching a sample: every output batch of SIGNAL_BATCH_ROWS rows is a patched
+    copy of pyarrow's own message metadata, the 16-byte ids / offsets / sample counts of its rows (3 KB, from the shards' memory
+    maps) and the rows' stored bytes, which are consecutive in their shard and move by copy_file_range on `threads` threads
+    (merge.copy_ranges).  Only the reads table (signal-row indices shifted by the rows of the earlier shards, dictionaries united;
+    columnar, no per-read object), the run-info table and the two footers are built anew.  The result is byte for byte what
+    Pod5FileWriter writes when it is handed all the reads in turn.  take_first: the first shard BECOMES the output (its full signal
+    batches stay where they are; the shard files are consumed).  -> number of reads; merge_pod5.last holds bytes / seconds."""
+    import os
+    import time
+    from . import merge as M
+    t0 = time.perf_counter()
+    pa = _pa()
+    threads = threads or M.merge_threads()
+    shards = [_Shard(p_) for p_ in paths]
+    try:
+        sig_schemas = [s_.table(CT_SIGNAL).schema for s_ in shards]
+        st = sig_schemas[0].field("signal").type
+        vbz = pa.types.is_large_binary(st.storage_type if isinstance(st, pa.ExtensionType) else st)
+        for p_, sc in zip(paths[1:], sig_schemas[1:]):
+            if sc.remove_metadata() != sig_schemas[0].remove_metadata():
+                raise ValueError(f"{p_}: signal table schema differs from {paths[0]} (VBZ and uncompressed shards do not mix)")
+        if take_first:
+            file_identifier, section_marker = shards[0].footer["file_identifier"], bytes(shards[0].marker)
+        file_identifier = file_identifier or uuid.uuid4()
+        marker = section_marker or uuid.uuid4().bytes
+        meta = {"MINKNOW:file_identifier": str(file_identifier), "MINKNOW:software": SOFTWARE, "MINKNOW:pod5_version": POD5_VERSION}
+        schema = _signal_schema(pa, meta, vbz)
+        width = 1 if vbz else 2
+
+        # ---- every signal row of every shard, in output order
+        per = [s_.signal_rows(vbz) for s_ in shards]
+        n_rows = [len(p_[1]) for p_ in per]
+        ids, counts = np.concatenate([p_[0] for p_ in per]), np.concatenate([p_[1] for p_ in per])
+        lens, pos = np.concatenate([p_[2] for p_ in per]), np.concatenate([p_[3] for p_ in per])
+        shard_of = np.repeat(np.arange(len(shards)), n_rows)
+        n = len(counts)
+        R = SIGNAL_BATCH_ROWS
+        n_batches = -(-n // R)
+        first_row = np.arange(n_batches, dtype=np.int64) * R
+        cum = np.concatenate([[0], np.cumsum(lens)])                       # in bytes (VBZ) or samples
+        data_units = cum[np.minimum(first_row + R, n)] - cum[first_row]
+        data_bytes = width * data_units
+
+        # ---- layout: head | batch messages | tail
+        head, msg_full, m_full, bufs_full = _signal_template(pa, schema, vbz, R)
+        k_last = n - (n_batches - 1) * R if n_batches else 0
+        tmpl = {R: (msg_full, m_full, bufs_full)}
+        if n_batches and k_last != R:
+            tmpl[k_last] = _signal_template(pa, schema, vbz, k_last)[1:]
+        di = 4 if vbz else 5                                               # the buffer that holds the rows' data
+        sig_start = len(SIGNATURE) + 16
+        msg_at = np.zeros(n_batches + 1, np.int64)                         # from the start of the embedded file
+        body_len, data_at = np.zeros(n_batches, np.int64), np.zeros(n_batches, np.int64)
+        for b in range(n_batches):
+            msg, m, bufs = tmpl[R if b < n_batches - 1 or k_last == R else k_last]
+            grow = _pad8(int(data_bytes[b])) - _pad8(int(bufs[di, 1]))
+            body_len[b] = len(msg) - m["meta"] + grow
+            data_at[b] = m["meta"] + bufs[di, 0]
+            msg_at[b + 1] = m["meta"] + body_len[b]
+        msg_at = len(head) + np.concatenate([[0], np.cumsum(msg_at[1:])])
+        blocks = np.zeros(n_batches, _BLOCK)
+        blocks["offset"], blocks["body"] = msg_at[:-1], body_len
+        blocks["meta"] = [tmpl[R if b < n_batches - 1 or k_last == R else k_last][1]["meta"] for b in range(n_batches)]
+        tail = _arrow_tail(pa, schema, blocks)
+
+        # ---- the data runs: rows that follow each other in a shard batch AND in an output batch move as one range
+        batch_of = np.arange(n, dtype=np.int64) // R
+        dst = sig_start + msg_at[batch_of] + data_at[batch_of] + width * (cum[:-1] - cum[first_row][batch_of]) if n else np.zeros(0, np.int64)
+        nbytes = width * lens
+        brk = np.ones(n, bool)
+        if n > 1:
+            brk[1:] = (batch_of[1:] != batch_of[:-1]) | (shard_of[1:] != shard_of[:-1]) | (pos[1:] != pos[:-1] + nbytes[:-1])
+        run = np.flatnonzero(brk)
+        run_bytes = np.add.reduceat(nbytes, run) if n else np.zeros(0, np.int64)
+
+        # ---- take_first: full batches of shard 0 stay in place (same head, same messages: the layout above IS shard 0's layout)
+        keep = 0
+        if take_first:
+            own = _arrow_blocks(shards[0].buf, *shards[0].at[CT_SIGNAL])[0]
+            keep = min(n_rows[0] // R, n_batches)
+            if shards[0].at[CT_SIGNAL][0] != sig_start or (keep and (
+                    not np.array_equal(own["offset"][:keep], blocks["offset"][:keep]) or
+                    not np.array_equal(own["body"][:keep], blocks["body"][:keep]))):
+                raise ValueError(f"{paths[0]}: signal table is not laid out as this writer lays it out; merge without take_first")
+        moving = batch_of[run] >= keep
+        in_place = [(int(shard_of[i]), int(pos[i]), int(dst[i]), int(nb)) for i, nb in zip(run[moving], run_bytes[moving])
+                    if take_first and shard_of[i] == 0]
+        stash = [(d, bytes(shards[0].buf[p_:p_ + nb])) for _, p_, d, nb in in_place]   # the one partial batch of shard 0: <= R rows
+        # (the tables behind shard 0's signal table are read before take_first lets the copies run over them)
+        cols, run_ids, run_infos, pore_types = _merged_read_columns(pa, shards, n_rows)
+        del per
+
+        with M._Files() as files, ThreadPoolExecutor(max_workers=1) as background:
+            if take_first:
+                os.replace(paths[0], out)
+                fd = files.open(out, os.O_RDWR)
+            else:
+                fd = files.open(out, os.O_RDWR | os.O_CREAT | os.O_EXCL)
+                os.pwrite(fd, SIGNATURE + marker + head, 0)
+            end_of_batches = sig_start + int(msg_at[-1])
+            os.ftruncate(fd, max(end_of_batches, os.fstat(fd).st_size))       # (grown at once; cut to its final size below)
+            jobs = [(shards[int(shard_of[i])].fd, int(pos[i]), fd, int(dst[i]), int(nb))
+                    for i, nb in zip(run[moving], run_bytes[moving]) if not (take_first and shard_of[i] == 0)]
+            copying = background.submit(M.copy_ranges, jobs, threads)
+            # the small parts of every batch that moves: message metadata + ids + offsets in front of the data, sample counts behind
+            for b in range(keep, n_batches):
+                lo, hi = b * R, min(b * R + R, n)
+                msg, m, bufs = tmpl[hi - lo]
+                part = bytearray(msg)
+                grow = _pad8(int(data_bytes[b])) - _pad8(int(bufs[di, 1]))
+                nb = bufs.copy()
+                nb[di, 1] = data_bytes[b]
+                nb[di + 1:, 0] += grow
+                part[m["buffers"][0]: m["buffers"][0] + nb.size * 8] = nb.tobytes()
+                struct.pack_into("<q", part, m["body_len"], int(body_len[b]))
+                if not vbz:                                                  # FieldNode of the list's child: its length is the sample count
+                    struct.pack_into("<q", part, m["nodes"][0] + 16 * 2, int(data_units[b]))
+                o = m["meta"]
+                part[o + bufs[1, 0]: o + bufs[1, 0] + 16 * (hi - lo)] = ids[lo:hi].tobytes()
+                part[o + bufs[3, 0]: o + bufs[3, 0] + 8 * (hi - lo + 1)] = (cum[lo:hi + 1] - cum[lo]).astype("<i8").tobytes()
+                front = o + int(bufs[di, 0])
+                back = front + _pad8(int(bufs[di, 1]))                       # the template's data (one unit per row) is cut out
+                last = o + int(bufs[-1, 0])
+                part[last: last + 4 * (hi - lo)] = counts[lo:hi].astype("<u4").tobytes()
+                at = sig_start + int(msg_at[b])
+                os.pwrite(fd, bytes(part[:front]), at)
+                os.pwrite(fd, bytes(_pad8(int(data_bytes[b])) - int(data_bytes[b])) + bytes(part[back:]), at + front + int(data_bytes[b]))
+            copied = copying.result()
+            for d, blob in stash:
+                os.pwrite(fd, blob, d)
+            os.pwrite(fd, tail, end_of_batches)
+
+            # ---- reads + run-info tables, footer
+            with os.fdopen(os.dup(fd), "r+b") as f:
+                f.seek(end_of_batches + len(tail))
+                f.truncate()
+                _write_tail(f, pa, meta, marker, file_identifier, sig_start, run_infos, cols, run_ids, pore_types)
+        merge_pod5.last = {"bytes_copied": int(copied) + sum(len(b_) for _, b_ in stash), "seconds": time.perf_counter() - t0,
+                           "signal_rows": int(n), "batches_in_place": int(keep)}
+        return len(cols["read_number"])
+    finally:
+        for s_ in shards:
+            try:
+                s_.close()
+            except (BufferError, OSError):
+                pass
+
+
+merge_pod5.last = {}
+
+
+def _merged_read_columns(pa, shards, n_rows):
+    """The reads tables of the shards as ONE set of columns (for _reads_table): signal-row indices shifted by the rows of the
+    earlier shards, pore-type and run-info dictionaries united (run infos in order of first appearance, by acquisition id)."""
+    names = [n for n, _ in READ_COLUMNS]
+    parts = {k: [] for k in names + ["read_id", "signal_rows", "pore_type", "end_reason", "run_info"]}
+    list_lens = []
+    run_ids, run_infos, pore_seen, pending = [], [], set(), []
+    base = 0
+    for s_, rows in zip(shards, n_rows):
+        t = s_.table(CT_READS).read_all()
+        runs = {ri["acquisition_id"]: ri for ri in s_.table(CT_RUN_INFO).read_all().to_pylist()}
+        for name, dt in READ_COLUMNS:
+            parts[name].append(t.column(name).to_numpy().astype(dt, copy=False) if t.num_rows else np.zeros(0, dt))
+        rid = t.column("read_id").combine_chunks()
+        rid = rid.storage if isinstance(rid, pa.ExtensionArray) else rid
+        parts["read_id"].append(np.frombuffer(rid.buffers()[1], np.uint8, 16 * len(rid), 16 * rid.offset).reshape(-1, 16)
+                                if len(rid) else np.zeros((0, 16), np.uint8))
+        sig = t.column("signal").combine_chunks()
+        offs = sig.offsets.to_numpy()
+        list_lens.append(np.diff(offs))
+        parts["signal_rows"].append(sig.values.to_numpy()[offs[0]:offs[-1]].astype(np.uint64) + np.uint64(base)
+                                    if len(sig) else np.zeros(0, np.uint64))
+        base += rows
+        for key in ("pore_type", "end_reason", "run_info"):
+            c = t.column(key).combine_chunks()
+            idx = c.indices.to_numpy().astype(np.int64) if len(c) else np.zeros(0, np.int64)
+            values = c.dictionary.to_pylist()
+            used = [values[i] for i in np.unique(idx)]
+            if key == "run_info":
+                for v in values:                                   # dictionary order = order of first appearance in the shard
+                    if v in used and v not in run_ids:
+                        run_ids.append(v)
+                        ri = dict(runs[v])
+                        ri["context_tags"], ri["tracking_id"] = dict(ri["context_tags"]), dict(ri["tracking_id"])
+                        run_infos.append(ri)
+                parts[key].append(np.array([run_ids.index(v) for v in values], np.int16)[idx] if len(idx) else np.zeros(0, np.int16))
+            elif key == "pore_type":
+                pore_seen.update(used)
+                pending.append((values, idx))
+            else:
+                remap = np.array([END_REASONS.index(v) for v in values], np.int16)
+                parts[key].append(remap[idx] if len(idx) else np.zeros(0, np.int16))
+    pore_types = sorted(pore_seen)
+    for values, idx in pending:
+        remap = np.array([pore_types.index(v) if v in pore_seen else -1 for v in values], np.int16)
+        parts["pore_type"].append(remap[idx] if len(idx) else np.zeros(0, np.int16))
+    cols = {k: (np.concatenate(v) if v else np.zeros(0)) for k, v in parts.items()}
+    cols["signal_offsets"] = np.concatenate([[0], np.cumsum(np.concatenate(list_lens))]).astype(np.int32) if list_lens else np.zeros(1, np.int32)
+    return cols, run_ids, run_infos, pore_types

@@ -418,95 +418,60 @@ def iter_blow5(path):
                "median_before": mb, "read_number": rn, "start_mux": mux, "start_time": st_}
 
 
-def merge_shards(paths, out: str) -> int:
-    """Concatenate BLOW5 (or SLOW5 ASCII) shard files with identical headers (POD5 shards: pod5_io.merge_pod5) -- the out.rankN files of a sharded run
-    (parallel.rank_output_path) -- into `out`: header of the first shard, every shard's records in order, one end-of-file marker.
-    Streams; nothing is decompressed.  -> number of records.  Header attributes that differ between shards (only the wall-clock
-    exp_start_time may) are taken from the first."""
+def merge_shards(paths, out: str, threads: int = None, consume: bool = False) -> int:
+    """The out.rankN files of a sharded run (parallel.rank_output_path) -> the ONE file the reference writes (inference.py:65-79):
+    BLOW5 / SLOW5 shards with identical headers (header of the first, every shard's records in order, one end-of-file marker),
+    POD5 shards by pod5_io.merge_pod5.  Nothing is decompressed and no record passes through the interpreter: the payload moves as
+    byte ranges on `threads` copy threads (merge.py).  consume=True: the first shard becomes the output and the others are
+    removed (what `predict --gpus N` does).  -> number of records; merge_shards.last = {"seconds", "bytes_copied", "bytes"}.
+    Header attributes that differ between shards (only the wall-clock exp_start_time may) are taken from the first."""
+    from . import merge as M
+    paths = list(paths)
     if not paths:
         raise ValueError("no shard files given")
     missing = [p_ for p_ in paths if not os.path.exists(p_)]
     if missing:
         raise FileNotFoundError(f"shard file(s) missing: {', '.join(missing)}")
+    pod5 = all(p_.endswith(".pod5") for p_ in paths)
+    binary = [p_.endswith(".blow5") for p_ in paths]
+    if pod5:
+        if not out.endswith(".pod5"):
+            raise ValueError("POD5 shards merge into a .pod5 file")
+        if os.path.exists(out):
+            raise FileExistsError(f"{out} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
+    elif any(b != binary[0] for b in binary) or (not binary[0] and not all(p_.endswith(".slow5") for p_ in paths)):
+        raise ValueError("shards must be all .blow5, all .slow5 or all .pod5")
     ext = os.path.splitext(out)[1]
     tmp = out[:len(out) - len(ext)] + ".partial" + ext              # the merged file appears under its name only when it is whole
     if os.path.exists(tmp):
         os.remove(tmp)
+    take_first = consume and (pod5 or binary[0])
     try:
-        n = _merge_shards_into(paths, tmp, out)
+        if pod5:
+            from .pod5_io import merge_pod5
+            n = merge_pod5(paths, tmp, threads=threads, take_first=take_first)
+            stats = dict(merge_pod5.last)
+        elif binary[0]:
+            n, stats = M.merge_blow5(paths, tmp, threads=threads, take_first=take_first)
+        else:
+            n, stats = M.merge_slow5(paths, tmp, threads=threads)
+        stats["bytes"] = os.path.getsize(tmp)
         os.replace(tmp, out)
-    finally:
-        if os.path.exists(tmp):
+    except BaseException:
+        if take_first and os.path.exists(tmp) and not os.path.exists(paths[0]):
+            # the first shard had already become the partial output: it is no shard any more, say where the bytes are
+            logger.error(f"merge failed after {paths[0]} was taken over as {tmp}; the other shard files are untouched")
+        elif os.path.exists(tmp):
             os.remove(tmp)
+        raise
+    if consume:
+        for p_ in paths[1 if take_first else 0:]:
+            os.remove(p_)
+    merge_shards.last = stats
     return n
 
 
-def _merge_shards_into(paths, out: str, final_name: str) -> int:
-    if all(p_.endswith(".pod5") for p_ in paths):
-        if not final_name.endswith(".pod5"):
-            raise ValueError("POD5 shards merge into a .pod5 file")
-        if os.path.exists(final_name):
-            raise FileExistsError(f"{final_name} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
-        from .pod5_io import merge_pod5
-        return merge_pod5(paths, out)
-    binary = [p_.endswith(".blow5") for p_ in paths]
-    if any(b != binary[0] for b in binary) or (not binary[0] and not all(p_.endswith(".slow5") for p_ in paths)):
-        raise ValueError("shards must be all .blow5, all .slow5 or all .pod5")
-    n = 0
-    if not binary[0]:
-        with open(out, "w") as fo:
-            for i, p_ in enumerate(paths):
-                with open(p_) as fi:
-                    for line in fi:
-                        if line.startswith(("#", "@")):
-                            if i == 0:
-                                fo.write(line)
-                            continue
-                        fo.write(line)
-                        n += 1
-        return n
-
-    def layout(f):
-        head = f.read(68)
-        if head[:6] != b"BLOW5\x01":
-            raise ValueError(f"{f.name}: not a BLOW5 file")
-        hlen = struct.unpack_from("<I", head, 64)[0]
-        return head, hlen
-
-    with open(out, "wb") as fo:
-        first = None
-        for i, p_ in enumerate(paths):
-            size = os.path.getsize(p_)
-            with open(p_, "rb") as fi:
-                head, hlen = layout(fi)
-                text = fi.read(hlen)
-                if i == 0:
-                    first = (head[:64], [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")])
-                    fo.write(head + text)
-                else:
-                    same = [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]
-                    if head[:64] != first[0] or same != first[1]:
-                        raise ValueError(f"{p_}: header differs from {paths[0]} (another profile, compression or run?)")
-                fi.seek(size - len(BLOW5Writer._EOF))
-                if fi.read() != BLOW5Writer._EOF:
-                    raise ValueError(f"{p_}: no end-of-file marker (truncated shard?)")
-                # count the records while copying them: [u64 size][body] ...
-                pos, end = 68 + hlen, size - len(BLOW5Writer._EOF)
-                fi.seek(pos)
-                while pos < end:
-                    (rec,) = struct.unpack("<Q", fi.read(8))
-                    fo.write(struct.pack("<Q", rec))
-                    left = rec
-                    while left:
-                        blk = fi.read(min(left, 1 << 24))
-                        if not blk:
-                            raise ValueError(f"{p_}: truncated record")
-                        fo.write(blk)
-                        left -= len(blk)
-                    pos += 8 + rec
-                    n += 1
-        fo.write(BLOW5Writer._EOF)
-    return n
+merge_shards.last = {}
 
 
 def read_slow5(path):

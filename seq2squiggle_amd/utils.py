@@ -89,6 +89,8 @@ def _read_fasta_native(path, map_acgtn: bool = False, limit: int = 4 << 30):
             return None                      # the records of this path are all in memory at once: larger files keep the streaming loop
         from ._lib import lib
         L = lib()
+        if not all(hasattr(L, f) for f in ("s2s_fasta_count", "s2s_fasta_clean", "s2s_fastq_clean")):
+            return None                      # an older library selected with S2S_HIP_LIB (_lib.py binds leniently then): the line loop
         data = np.memmap(path, dtype=np.uint8, mode="r")
     except Exception:
         return None
@@ -270,6 +272,8 @@ def replay_sampler(num_seqs, genome_seqs, genome_lens, r, seed, total_len, distr
         from ._lib import lib
         L = lib()
     except (RuntimeError, OSError):
+        return None
+    if not hasattr(L, "s2s_sampler_replay_law"):      # an older library selected with S2S_HIP_LIB: replay in the interpreter
         return None
     version, internal, gauss = random.getstate()
     if version != 3 or len(internal) != 625:

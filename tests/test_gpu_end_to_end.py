@@ -382,3 +382,46 @@ def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
     print(f"two ranks on one GPU: {e['chunks_per_sec']:.3e} chunks/s end to end ({e['per_rank_cpu_share_threads'][0]} host threads per rank) "
           f"vs one rank {single['chunks_per_sec']:.3e}: x{ratio:.2f}")
     assert ratio > 0.7, (e, single)          # measured 0.99-1.04; a host-side collapse under halved thread counts would read <= 0.5
+
+
+def test_a_run_far_above_the_redo_threshold_on_the_fast_path_says_so(tmp_path, caplog):
+    """the calibration launch decides the attention path on 512 pseudo-random chunks; a RUN that ends on the
+    fast path with more than 8 % of its heads redone (here: the decoder's w_qs / w_ks x 4 forced onto the fast path, 79 %) logs a
+    WARNING that names `--attention-path exact` -- at the default verbosity, not at debug -- and the output is the file the exact
+    path writes (no run-time switching: a chunk's result never depends on its batch).  The committed checkpoint says nothing."""
+    import logging
+    from seq2squiggle_amd.cli import set_config
+    ck = torch.load(os.path.join(GOLDEN, "synthetic_k9.ckpt"), map_location="cpu", weights_only=True)
+    for k in ck["state_dict"]:
+        if k.startswith("decoders.") and k.endswith(("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")):
+            ck["state_dict"][k] = ck["state_dict"][k] * 4.0
+    sharp = str(tmp_path / "sharp.ckpt")
+    torch.save(ck, sharp)
+    lam = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+
+    def run(weights, out, path):
+        caplog.clear()
+        with caplog.at_level(logging.INFO, logger="seq2squiggle"):
+            m = inference_run(config=set_config(None), saved_weights=weights, fasta=lam, read_input=False, n=12, r=1500, c=-1,
+                              out=str(out), profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True,
+                              duration_sampling=True, distr="expon", predict_batch_size=1024, export_every_n_samples=1000000,
+                              sample_rate=None, bps=None, digitisation=None, range_val=None, offset_mean=None, offset_std=None,
+                              median_before_mean=None, median_before_std=None, min_noise=0.0, min_duration=3, min_read_len=30,
+                              preserve_read_ids=False, seed=9, attention_path=path)
+        warned = [r for r in caplog.records if r.levelno == logging.WARNING and "--attention-path exact" in r.getMessage()]
+        return m, warned
+    m, warned = run(sharp, tmp_path / "fast.blow5", "fast")
+    assert len(warned) == 1 and m.run_stats["attention_path"] == "fast" and m.run_stats["redo_rate"] > 0.5
+    assert "%" in warned[0].getMessage()
+    m, warned = run(sharp, tmp_path / "auto.blow5", "auto")              # the calibration sends these weights to the exact instance: nothing to warn about
+    assert not warned and m.run_stats["attention_path"] == "exact" and m.run_stats["softmax_redone"] == 0
+    m, warned = run(os.path.join(GOLDEN, "synthetic_k9.ckpt"), tmp_path / "plain.blow5", "auto")
+    assert not warned and m.run_stats["attention_path"] == "fast" and m.run_stats["redo_rate"] < 0.01
+    a, b = signal_io.read_blow5(str(tmp_path / "fast.blow5"))[1], signal_io.read_blow5(str(tmp_path / "auto.blow5"))[1]
+    assert len(a) == len(b) == 12
+    for x, y in zip(a, b):                                              # two roundings of the same softmax: the same int16 samples but for ties
+        assert x["len_raw_signal"] == y["len_raw_signal"]
+        d = np.abs(x["signal"].astype(np.int32) - y["signal"].astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 0.01
+    with pytest.raises(ValueError, match="attention_path"):
+        run(sharp, tmp_path / "x.blow5", "sideways")

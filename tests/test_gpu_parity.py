@@ -18,6 +18,17 @@ pytestmark = pytest.mark.gpu
 MAE_TOL, MAX_TOL = 1e-4, 2e-3
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _no_attention_path_override():
+    """The tests below read what s2s_create's calibration launch decided: an S2S_ATTENTION_PATH left in the caller's environment
+    would skip that launch (calibration_redo_rate = -1) for every engine of the module."""
+    import os
+    saved = os.environ.pop("S2S_ATTENTION_PATH", None)
+    yield
+    if saved is not None:
+        os.environ["S2S_ATTENTION_PATH"] = saved
+
+
 def P(**kw):
     base = dict(dwell_mean=12.5, dwell_std=0.0, noise_std=2.0, noise_sampling=True, duration_sampling=True,
                 min_noise=0.0, min_duration=3.0)
@@ -264,9 +275,26 @@ def test_attention_path_calibration_and_overrides(monkeypatch):
     def scaled(f):
         return {k: (v * f if k.startswith("decoders.") and k.endswith(("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")) else v.clone())
                 for k, v in sd.items()}
-    eng = S.Engine(scaled(2.0), cfg, mode="f16x3")                 # 59 % of the heads redone with pass 0 = the first 64 keys (round 3);
-    assert eng.attention_path == "fast" and 0.03 < eng.calibration_redo_rate < 0.08   # 6.4 % with pass 0 a sample of the whole row
-    eng.close()
+    from oracle import redo_model as R
+    gi = torch.from_numpy(g["g"])
+    for f in (1.0, 2.0, 4.0):
+        # the decision rule, and the kernel's redo counter on the golden chunks against the CPU model of the fast path on the same
+        # chunks (oracle/redo_model.py: rows whose maximum beats their pass-0 maximum by more than 18 log2 units; pass 0 = the key
+        # blocks b = 0 mod 4).  x 2: 59 % with pass 0 = the first 64 keys (round 3), 6-7 % now -- near the 8 % threshold, which is
+        # why the RATE is compared with the model instead of being pinned to a window that decides the path
+        eng = S.Engine(scaled(f), cfg, mode="f16x3")
+        assert (eng.attention_path == "exact") == (eng.calibration_redo_rate > 0.08) and 0.0 <= eng.calibration_redo_rate <= 1.0
+        eng.attention_path = "fast"
+        eng.stats()
+        eng.predict_chunks(b, n, S.PredictParams(**P(noise_std=0.0)), inject_g=gi.cuda())
+        measured = eng.stats()["redo_rate"]
+        model = R.predicted_redo_rate(scaled(f), cfg, g["codes"], gi)
+        first64 = R.predicted_redo_rate(scaled(f), cfg, g["codes"], gi, scheme="first64")
+        print(f"REDO x{f:g}: calibration {eng.calibration_redo_rate:.4f}, golden chunks measured {measured:.4f}, model {model:.4f} (first 64 keys: {first64:.4f})")
+        assert abs(measured - model) <= max(0.02, 0.35 * model), (f, measured, model)
+        if f == 2.0:
+            assert 0.0 < measured < 0.25 < first64                 # the interleaved pass 0 is what keeps this checkpoint off the redo path
+        eng.close()
     sharp = scaled(4.0)
     rates = []
     for _ in range(2):
@@ -284,12 +312,21 @@ def test_attention_path_calibration_and_overrides(monkeypatch):
         assert torch.equal(a["dur"], c["dur"]) and float((a["signal"] - c["signal"]).abs().mean()) < MAE_TOL
         eng.close()
     assert rates[0] == rates[1]                                   # a fixed input: deterministic per set of weights
-    for env, want in (("fast", "fast"), ("exact", "exact")):
+    for env, want in (("fast", "fast"), ("exact", "exact"), ("Exact", "exact"), ("FAST", "fast")):
         monkeypatch.setenv("S2S_ATTENTION_PATH", env)
         for weights in (sd, sharp):
             eng = S.Engine(weights, cfg, mode="f16x3")
             assert eng.attention_path == want and eng.calibration_redo_rate == -1.0      # no calibration launch
             eng.close()
+    for env in ("auto", ""):                                      # ... means: calibrate
+        monkeypatch.setenv("S2S_ATTENTION_PATH", env)
+        eng = S.Engine(sharp, cfg, mode="f16x3")
+        assert eng.attention_path == "exact" and eng.calibration_redo_rate == rates[0]
+        eng.close()
+    for env in ("sideways", "e", "1", "exactly"):                 # a typo must not pin a path silently
+        monkeypatch.setenv("S2S_ATTENTION_PATH", env)
+        with pytest.raises(RuntimeError, match="S2S_ATTENTION_PATH"):
+            S.Engine(sd, cfg, mode="f16x3")
     monkeypatch.delenv("S2S_ATTENTION_PATH")
     eng = S.Engine(sharp, cfg, mode="f32")                        # the f32 block has one softmax path
     eng.predict_chunks(b, n, S.PredictParams(**P(seed=5)))
@@ -622,12 +659,16 @@ def test_other_layer_counts(mode, enc_l, dec_l, pre_l):
 
 @pytest.mark.parametrize("tag", ["k9", "k6"])
 def test_reduced_precision_f16_mode(tag):
-    """S2S_MODE_F16 (decoder operands rounded to f16 once, one MFMA product per product; the precision class of the
-    reference's own fp16-autocast GPU path, inference.py:404) is OUTSIDE the 1e-4 pA parity bound by design.  What it
-    must keep: dwell indices bit-exact (the frontend stays f16x3), signal MAE < 0.05 pA / max < 0.5 pA against the fp32
-    goldens, and the zero pattern except where the pre-ReLU value is within that error of zero."""
+    """S2S_MODE_F16 (decoder operands rounded to f16 once, one MFMA product per product) is OUTSIDE the 1e-4 pA parity bound by
+    design.  Its bar is the reference's OWN GPU arithmetic: inference.py:403-404 runs "16-mixed" whenever a GPU is present, and
+    tests/golden/mixed16.npz holds the imported reference's predict_step under fp16 autocast on these very chunks with the same
+    injected variates (tools/make_goldens.py mixed16).  The mode must be at least as close to the fp32 golden as that -- MAE and
+    max, measured where the reference's 16-mixed dwell indices agree with fp32's (one of its 816 / 896 indices rounds the other
+    way and shifts a whole chunk; the mode's own indices are bit-exact, the frontend stays f16x3) -- and keep the zero pattern
+    except where the pre-ReLU value is within that error of zero."""
     sd, cfg = load_ckpt(tag)
     g = load_npz(f"stages_{tag}.npz")
+    m16 = load_npz("mixed16.npz")
     bases, nv = chunker.codes_to_bases(g["codes"])
     eng = S.Engine(sd, cfg, mode="f16")
     b, n = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda()
@@ -638,5 +679,110 @@ def test_reduced_precision_f16_mode(tag):
     same = (y == 0) == (t == 0)
     assert same.mean() > 0.999
     d = np.abs(y - t)[same]
-    assert 1e-4 < d.mean() < 0.05 and d.max() < 0.5            # measurably not the parity path, and bounded
+    # the reference under 16-mixed, re-derived from the committed vectors (not from the scalars stored beside them)
+    r16, dur16 = m16[f"y_gamma_nsamp_16mixed_{tag}"], m16[f"dur_gamma_16mixed_{tag}"]
+    agree = (dur16 == g["dur_gamma"]).all(1)
+    assert 0 < (~agree).sum() <= 2 and int((dur16 != g["dur_gamma"]).sum()) == int(m16[f"dwell_indices_differing_{tag}"])
+    ref_d = np.abs(r16 - t)[agree]
+    assert abs(ref_d.mean() - float(m16[f"mae_vs_fp32_where_dwell_equal_{tag}"])) < 1e-6
+    print(f"F16MODE {tag}: mode MAE {d.mean():.4f} max {d.max():.3f} | reference 16-mixed MAE {ref_d.mean():.4f} max {ref_d.max():.3f} "
+          f"(all chunks: {np.abs(r16 - t).mean():.4f} / {np.abs(r16 - t).max():.1f})")
+    assert 1e-4 < d.mean() <= ref_d.mean() and d.max() <= ref_d.max()      # measurably not the parity path; no worse than the reference's GPU path
     eng.close()
+
+
+QK = ("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")
+
+
+def _variant(sd, kind):
+    """Checkpoints that make the fast softmax path redo SOME heads: "x2" = the decoder's w_qs / w_ks doubled; "pos2" / "pos3" =
+    attention on the positional encoding alone (w_qs = w_ks = c I, biases 0: scores follow the sinusoid table, local attention)."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for k in out:
+        if k.startswith("decoders.") and k.endswith(QK):
+            if kind == "x2":
+                out[k] = out[k] * 2.0
+            else:
+                c = float(kind[3:])
+                out[k] = c * torch.eye(64) if k.endswith("weight") else torch.zeros(64)
+    return out
+
+
+def _parity_both_paths(sd, cfg, reads, label, want_mixed=None):
+    """reads -> chunks -> fast and exact path against the fp32 and fp64 oracle (dwell indices and zero pattern exact, signal within
+    the parity bound or within 5 x the fp32 oracle's own distance to fp64 where near-one-hot rows amplify rounding).
+    -> (calibration redo rate, redo rate of this input on the fast path, the CPU model's)."""
+    from oracle import redo_model as R
+    k = cfg["seq_kmer"]
+    bases, nv, _ = S.encode_reads(reads, k)
+    codes = np.concatenate([O.encode_read(r, k) for r in reads], 0)
+    B = bases.shape[0]
+    gen = torch.Generator().manual_seed(11)
+    gi = torch.rand(B, 16, generator=gen) * 20
+    p = P(noise_std=0.0)
+    ref = O.predict_chunks(sd, cfg, codes, O.PredictParams(**p), inject_g=gi)
+    ref64 = O.predict_chunks(sd, cfg, codes, O.PredictParams(**p), inject_g=gi, dtype=torch.float64)
+    r, t = ref["signal"].numpy(), ref64["signal"].numpy()
+    agree64 = (r == 0) == (t == 0)
+    err_ref = np.abs(r - t)[agree64].mean()
+    eng = S.Engine(sd, cfg, mode="f16x3")
+    calib = eng.calibration_redo_rate
+    b_d, n_d, g_d = torch.from_numpy(bases).cuda(), torch.from_numpy(nv).cuda(), gi.cuda()
+    live = None
+    for path in ("fast", "exact"):
+        eng.attention_path = path
+        eng.stats()
+        out = eng.predict_chunks(b_d, n_d, S.PredictParams(**p), inject_g=g_d)
+        y = out["signal"].cpu().numpy()
+        st = eng.stats()
+        assert st["chunks"] == B and st["softmax_runs"] == B * 8 * 8 * cfg["decoder_layers"]
+        assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy()), (label, path)
+        same = (y == 0) == (r == 0)
+        assert same.mean() > 0.9995, (label, path, same.mean())
+        mae, mx = np.abs(y - r)[same].mean(), np.abs(y - r)[same].max()
+        err_gpu = np.abs(y - t)[same & agree64].mean()
+        assert (mae < MAE_TOL and mx < MAX_TOL) or err_gpu < 5 * err_ref, (label, path, mae, mx, err_gpu, err_ref)
+        if path == "fast":
+            live = st["redo_rate"]
+            if want_mixed:
+                assert 0 < st["softmax_redone"] < 0.5 * st["softmax_runs"], (label, st)      # some heads of a launch redone, their partners not
+        else:
+            assert st["softmax_redone"] == 0 and st["chunks_on_exact_path"] == B
+        print(f"MIXED {label} {path}: {B} chunks, redo {st['redo_rate']:.4f} (calibration {calib:.4f}), MAE {mae:.2e} max {mx:.2e} "
+              f"vs fp64 {err_gpu:.2e} (fp32 oracle vs fp64 {err_ref:.2e})")
+    eng.close()
+    model = R.predicted_redo_rate(sd, cfg, codes, gi)
+    assert abs(live - model) <= max(0.02, 0.35 * model), (label, live, model)
+    return calib, live, model
+
+
+@pytest.mark.parametrize("kind", ["x2", "pos2", "pos3"])
+@pytest.mark.parametrize("tag", ["k9", "k6"])
+def test_mixed_redo_regime_against_the_oracle(tag, kind):
+    """the regime in which SOME heads of a launch are redone by the fast instance's out-of-line online softmax
+    while their partner waves are not (the tested cases were 0 % and >= 79 % redone) -- against the fp32 and fp64 oracle, on both
+    attention paths, on 240 chunks of random and lambda-genome sequence.  Reference: layers.py:20-40."""
+    from oracle import redo_model as R
+    sd, cfg = load_ckpt(tag)
+    fam = R.input_families(seed=3, n_reads=5, read_len=384)
+    reads = fam["random"] + fam["lambda"]
+    _parity_both_paths(_variant(sd, kind), cfg, reads, f"{tag}-{kind}", want_mixed=True)
+
+
+@pytest.mark.parametrize("tag", ["k9", "k6", "k9-x2"])
+def test_redo_share_depends_on_the_input_and_parity_holds(tag):
+    """the calibration launch decides on 512 pseudo-random chunks, but the redo share is a property of the
+    weights AND the reads.  Real sequence (lambda), homopolymers, di- / tri-nucleotide repeats and N-rich reads through the
+    committed checkpoints (and the x 2 one, which sits near the threshold): parity holds on both paths for every family, and the
+    live redo share is reported beside the calibration's and the CPU model's (tools/redo_inputs.py prints the same table;
+    inference_run warns when a run on the fast path ends above the threshold)."""
+    from oracle import redo_model as R
+    sd, cfg = load_ckpt(tag[:2])
+    if tag.endswith("-x2"):
+        sd = _variant(sd, "x2")
+    rows = {}
+    for name, reads in R.input_families(seed=5, n_reads=4, read_len=320).items():
+        rows[name] = _parity_both_paths(sd, cfg, reads, f"{tag}-{name}")
+    print("REDO_BY_INPUT", tag, {k: tuple(round(x, 4) for x in v) for k, v in rows.items()})
+    if tag != "k9-x2":
+        assert all(live < 0.08 for _, live, _ in rows.values()), rows      # the committed checkpoints stay on the fast path for every family

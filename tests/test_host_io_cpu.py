@@ -538,18 +538,194 @@ def test_merge_pod5_shards_equals_the_single_process_file(tmp_path):
         signal_io.merge_shards(shards, str(tmp_path / "x.blow5"))
 
 
+def _write_shards(tmp_path, ext, lens, splits, rng, signal_compression=None, tag="o"):
+    prof = U.get_profile("dna-r10-prom")
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = (600 + 40 * rng.standard_normal(offs[-1])).astype(np.int16)
+    ids = [f"read{i}" for i in range(len(lens))]
+    shards = []
+    for r, (lo, hi) in enumerate(splits):
+        np.random.seed(8)
+        path = parallel.rank_output_path(str(tmp_path / f"{tag}.{ext}"), r, len(splits))
+        if ext == "pod5":
+            from seq2squiggle_amd import pod5_io
+            w = signal_io.POD5Writer(path, prof, False, "dna-r10-prom", False)
+            w._stream = pod5_io.Pod5FileWriter(path, signal_compression=signal_compression)
+            if lo:
+                w.start_at(lo)
+            w.write_records(w.dac_records(ids[lo:hi], flat[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo]))
+            w.close()
+        else:
+            w = signal_io.BLOW5Writer(path, prof, False, "dna-r10-prom", False)
+            if lo:
+                w.start_at(lo)
+            w.save_dac(ids[lo:hi], flat[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo])
+        shards.append(path)
+    return shards
+
+
+_SHARD_SHAPES = [([5, 300, 102400, 102401, 250000, 17, 4000, 1, 64000], ((0, 3), (3, 3), (3, 9))),     # multi-row reads, an empty shard
+                 (None, ((0, 120), (120, 333), (333, 457))),                                             # partial batches at every seam
+                 (None, ((0, 100), (100, 200), (200, 300))),                                             # seams on batch boundaries
+                 (None, ((0, 0), (0, 30))),                                                              # empty FIRST shard
+                 ([7, 9], ((0, 1), (1, 2), (2, 2)))]
+
+
+@pytest.mark.parametrize("signal_compression", ["vbz", "none"])
+@pytest.mark.parametrize("shape", range(len(_SHARD_SHAPES)))
+def test_pod5_byte_range_merge_equals_the_read_by_read_merge(tmp_path, signal_compression, shape):
+    """merge_pod5 moves the signal rows as raw byte ranges (copy_file_range on threads) and re-batches the signal
+    table by patching pyarrow's own message metadata -- the file must be BYTE FOR BYTE what handing every read of every shard to a
+    fresh Pod5FileWriter produces (tests/_merge_serial.py: the merge of rounds 2-4), for VBZ and uncompressed signal tables, seams
+    inside and on batch boundaries, empty shards; take_first (shard 0 becomes the output, its full batches never move) as well."""
+    import shutil
+    import uuid as _uuid
+    import _merge_serial as serial
+    from seq2squiggle_amd import pod5_io
+    rng = np.random.default_rng(60 + shape)
+    lens, splits = _SHARD_SHAPES[shape]
+    if lens is None:
+        lens = list(rng.integers(1, 3000, splits[-1][1]))
+    shards = _write_shards(tmp_path, "pod5", lens, splits, rng, signal_compression)
+    fid, marker = _uuid.uuid4(), _uuid.uuid4().bytes
+    want = str(tmp_path / "want.pod5")
+    n = serial.merge_pod5_rebuild(shards, want, fid, marker, signal_compression)
+    for threads in (1, 3):
+        got = str(tmp_path / f"got{threads}.pod5")
+        assert pod5_io.merge_pod5(shards, got, threads=threads, file_identifier=fid, section_marker=marker) == n == len(lens)
+        assert open(got, "rb").read() == open(want, "rb").read()
+    assert pod5_io.merge_pod5.last["signal_rows"] == sum(-(-int(x) // pod5_io.SIGNAL_CHUNK) for x in lens)
+    # take_first: identity and marker are shard 0's
+    own = pod5_io.read_pod5(shards[0])["footer"]["file_identifier"]
+    own_marker = open(shards[0], "rb").read()[8:24]
+    want2 = str(tmp_path / "want2.pod5")
+    serial.merge_pod5_rebuild(shards, want2, own, own_marker, signal_compression)
+    copies = [shutil.copy(p_, p_ + ".copy.pod5") for p_ in shards]
+    assert signal_io.merge_shards(copies, str(tmp_path / "taken.pod5"), threads=2, consume=True) == n
+    assert open(tmp_path / "taken.pod5", "rb").read() == open(want2, "rb").read()
+    assert not any(os.path.exists(c) for c in copies)
+    rows = lambda xs: sum(-(-int(x) // pod5_io.SIGNAL_CHUNK) for x in xs)
+    assert signal_io.merge_shards.last["batches_in_place"] == min(rows(lens[splits[0][0]:splits[0][1]]) // pod5_io.SIGNAL_BATCH_ROWS,
+                                                                  -(-rows(lens) // pod5_io.SIGNAL_BATCH_ROWS))
+    # and it reads back as the reads of the shards, in order
+    back = pod5_io.read_pod5(str(tmp_path / "taken.pod5"))
+    assert [len(r["signal"]) for r in back["reads"]] == [int(x) for x in lens]
+    assert [r["read_number"] for r in back["reads"]] == list(range(len(lens)))
+
+
+@pytest.mark.parametrize("ext", ["blow5", "slow5"])
+def test_blow5_byte_range_merge_equals_the_record_by_record_merge(tmp_path, ext):
+    """The BLOW5 / SLOW5 merge copies each shard's record section as ONE range to its prefix-sum offset: byte-equal to the
+    record-by-record copy of rounds 2-4; consume=True (first shard becomes the output) gives the same bytes and removes the shards;
+    the record count comes from the size prefixes (s2s_blow5_scan) and doubles as the truncation check."""
+    import shutil
+    import _merge_serial as serial
+    rng = np.random.default_rng(5)
+    lens = list(rng.integers(3, 4000, 23))
+    for k, splits in enumerate((((0, 4), (4, 4), (4, 23)), ((0, 0), (0, 23)), ((0, 23),), ((0, 11), (11, 23), (23, 23)))):
+        shards = _write_shards(tmp_path, ext, lens, splits, rng, tag=f"s{k}")
+        want = str(tmp_path / f"want{k}.{ext}")
+        n = (serial.merge_blow5_serial if ext == "blow5" else serial.merge_slow5_serial)(shards, want)
+        for threads in (1, 4):
+            got = str(tmp_path / f"got{k}_{threads}.{ext}")
+            assert signal_io.merge_shards(shards, got, threads=threads) == n == 23
+            assert open(got, "rb").read() == open(want, "rb").read()
+            assert signal_io.merge_shards.last["bytes"] == os.path.getsize(want)
+        copies = [shutil.copy(p_, p_ + f".copy.{ext}") for p_ in shards]
+        assert signal_io.merge_shards(copies, str(tmp_path / f"taken{k}.{ext}"), consume=True) == n
+        assert open(tmp_path / f"taken{k}.{ext}", "rb").read() == open(want, "rb").read()
+        assert not any(os.path.exists(c) for c in copies)
+    if ext == "blow5":                       # a record whose size prefix points past the end-of-file marker
+        from seq2squiggle_amd import merge as M
+        bad = bytearray(open(shards[0], "rb").read())
+        _, _, begin, _ = M._blow5_layout(os.open(shards[0], os.O_RDONLY), shards[0])
+        bad[begin:begin + 8] = (1 << 40).to_bytes(8, "little")
+        (tmp_path / "bad.blow5").write_bytes(bytes(bad))
+        with pytest.raises(ValueError, match="truncated record"):
+            signal_io.merge_shards([shards[1], str(tmp_path / "bad.blow5")], str(tmp_path / "x.blow5"))
+        assert not os.path.exists(tmp_path / "x.blow5") and not os.path.exists(tmp_path / "x.partial.blow5")
+
+
+def test_copy_ranges_native_and_python_agree(tmp_path):
+    """merge.copy_ranges: s2s_copy_ranges (copy_file_range on native threads, bounce-buffer fallback) and the Python-thread
+    fallback used when the library is absent put the same bytes in the same places; zero-length jobs are ignored."""
+    from seq2squiggle_amd import merge as M
+    rng = np.random.default_rng(3)
+    src = tmp_path / "src.bin"
+    data = rng.integers(0, 256, 3_000_000, dtype=np.uint8).tobytes()
+    src.write_bytes(data)
+    spans = [(0, 10), (10, 0), (100_000, 1_234_567), (2_999_000, 1000), (5, 70_000)]
+    want = bytearray(4_000_000)
+    at, jobs_of = 17, []
+    for so, ln in spans:
+        want[at:at + ln] = data[so:so + ln]
+        jobs_of.append((so, at, ln))
+        at += ln + 3
+    outs = []
+    for name, hide in (("native", False), ("python", True)):
+        fs, fd = os.open(src, os.O_RDONLY), os.open(tmp_path / f"{name}.bin", os.O_RDWR | os.O_CREAT)
+        os.ftruncate(fd, len(want))
+        if hide:
+            import seq2squiggle_amd._lib as LB
+            real = LB.lib
+            LB.lib = lambda: (_ for _ in ()).throw(RuntimeError("hidden"))
+        try:
+            assert M.copy_ranges([(fs, so, fd, do, ln) for so, do, ln in jobs_of], threads=3) == sum(ln for _, ln in spans)
+        finally:
+            if hide:
+                LB.lib = real
+            os.close(fs)
+            os.close(fd)
+        outs.append(open(tmp_path / f"{name}.bin", "rb").read())
+    assert outs[0] == outs[1] == bytes(want)
+
+
 def test_predict_gpus_option_starts_one_rank_per_gpu():
-    """`predict --gpus N` outside torchrun re-launches the same command line under torch.distributed.run (children, never exec);
-    inside a rank (WORLD_SIZE set) the option is inert."""
+    """`predict --gpus N` outside torchrun starts the same command line once per GPU as child processes (never exec) with the
+    environment torchrun would give them; inside a rank (WORLD_SIZE set) the option is inert."""
     import json
     r = subprocess.run([sys.executable, "-m", "seq2squiggle_amd", "predict", "g.fa", "--gpus", "8", "-o", "o.pod5", "-c", "30",
                         "--gpus=8", "--seed", "7"], cwd=ROOT, capture_output=True, text=True,
                        env={k: v for k, v in dict(os.environ, S2S_DRY_LAUNCH="1").items() if k != "WORLD_SIZE"})
     assert r.returncode == 0, r.stderr
-    cmd = json.loads(r.stdout.strip().splitlines()[-1])["dry_launch"]
-    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert cmd[cmd.index("seq2squiggle_amd") + 1:] == ["predict", "g.fa", "-o", "o.pod5", "-c", "30", "--seed", "7"]
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd, envs = plan["dry_launch"], plan["rank_env"]
+    assert cmd[1:] == ["-m", "seq2squiggle_amd", "predict", "g.fa", "-o", "o.pod5", "-c", "30", "--seed", "7"]
+    assert len(envs) == 8 and [e["RANK"] for e in envs] == [e["LOCAL_RANK"] for e in envs] == [str(i) for i in range(8)]
+    assert all(e["WORLD_SIZE"] == e["LOCAL_WORLD_SIZE"] == "8" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1
+
+
+_RANK_STUB = r"""
+import json, os, sys, time
+# stands in for `python -m seq2squiggle_amd predict ...` inside a rank: writes what the parent reads, fails on request
+rank = int(os.environ["RANK"])
+if os.environ.get("STUB_FAIL_RANK") == str(rank):
+    sys.exit(7)
+if os.environ.get("STUB_FAIL_RANK") is not None:
+    time.sleep(30)                       # the parent must end this rank when its sibling fails
+with open(os.path.join(os.environ["S2S_TIMING_DIR"], "rank%d.json" % rank), "w") as f:
+    json.dump({"ready": time.time(), "done": time.time() + 0.01}, f)
+"""
+
+
+def test_launch_ranks_collects_timing_and_ends_siblings_on_failure(tmp_path, monkeypatch):
+    """cli._launch_ranks: N children with the rank environment; their ready / done stamps become launch_seconds / predict_seconds;
+    the first failing rank's exit code is returned and the others are ended (by pid) instead of running on."""
+    from seq2squiggle_amd import cli
+    stub = tmp_path / "stub.py"
+    stub.write_text(_RANK_STUB)
+    monkeypatch.setattr(sys, "argv", ["seq2squiggle_amd", "predict", "g.fa", "--gpus", "3", "-o", "o.blow5"])
+    monkeypatch.setattr(sys, "executable", sys.executable)
+    real_popen = subprocess.Popen
+    monkeypatch.setattr(subprocess, "Popen", lambda cmd, env=None, **kw: real_popen([cmd[0], str(stub)], env=env, **kw))
+    monkeypatch.delenv("S2S_DRY_LAUNCH", raising=False)
+    rc, timing = cli._launch_ranks(3)
+    assert rc == 0 and 0 <= timing["launch_seconds"] < 30 and 0 <= timing["predict_seconds"] < 1
+    monkeypatch.setenv("STUB_FAIL_RANK", "1")
+    t0 = __import__("time").time()
+    rc, timing = cli._launch_ranks(3)
+    assert rc == 7 and timing == {} and __import__("time").time() - t0 < 20
 
 
 _SEED_WORKER = r"""

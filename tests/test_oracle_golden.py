@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import s2s_oracle as O
-from conftest import load_npz
+from conftest import load_ckpt, load_npz
 
 torch.set_float32_matmul_precision("highest")
 TOL = 2e-6      # scaled units; two fp32 evaluation orders of the same aten ops
@@ -126,3 +126,40 @@ def test_dac_conversion_profiles():
         with np.errstate(all="ignore"):
             raw = O.to_dac(g["signal"], dig, rng, off, rna=n.startswith("rna"))
         assert np.array_equal(raw, g[n + "__raw"]), n
+
+
+def test_mixed16_vectors_are_what_the_docs_quote():
+    """tests/golden/mixed16.npz (tools/make_goldens.py mixed16: the imported reference's predict_step under fp16 autocast, the
+    arithmetic class inference.py:403-404 selects on a GPU): the stored distances are those of the stored vectors, one dwell
+    index per checkpoint rounds the other way, and on the other chunks the reference's own GPU-precision path sits 0.04 / 0.06 pA
+    from its fp32 result -- the bar of the engine's opt-in f16 mode (tests/test_gpu_parity.py)."""
+    m = load_npz("mixed16.npz")
+    for tag, lo, hi in (("k9", 0.03, 0.05), ("k6", 0.05, 0.07)):
+        g = load_npz(f"stages_{tag}.npz")
+        y16, y32, d16 = m[f"y_gamma_nsamp_16mixed_{tag}"], g["y_gamma_nsamp"], m[f"dur_gamma_16mixed_{tag}"]
+        assert y16.shape == y32.shape and d16.shape == g["dur_gamma"].shape
+        d = np.abs(y16 - y32)
+        agree = (d16 == g["dur_gamma"]).all(1)
+        assert int((d16 != g["dur_gamma"]).sum()) == int(m[f"dwell_indices_differing_{tag}"]) == 1
+        assert abs(d.mean() - float(m[f"mae_vs_fp32_{tag}"])) < 1e-7 and abs(d.max() - float(m[f"max_vs_fp32_{tag}"])) < 1e-4
+        assert abs(d[agree].mean() - float(m[f"mae_vs_fp32_where_dwell_equal_{tag}"])) < 1e-7
+        assert lo < d[agree].mean() < hi and d[agree].max() < 0.5
+        assert np.array_equal(y16 == 0, y32 == 0)
+
+
+def test_redo_model_reproduces_the_table_the_key_order_was_chosen_with():
+    """oracle/redo_model.py on the golden chunks: with pass 0 = the first 64 keys (rounds 1-3) the decoder's w_qs / w_ks x 2 redoes
+    more than half of its heads, with pass 0 = every 4th block of four keys (HEAD's fast instance) 5-9 %; the committed weights
+    nothing either way."""
+    from oracle import redo_model as R
+    sd, cfg = load_ckpt("k9")
+    g = load_npz("stages_k9.npz")
+    codes, gi = g["codes"][:24], torch.from_numpy(g["g"][:24])
+    x2 = {k: (v * 2.0 if k.startswith("decoders.") and k.endswith(("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")) else v.clone())
+          for k, v in sd.items()}
+    assert R.predicted_redo_rate(sd, cfg, codes, gi) == 0.0
+    assert R.predicted_redo_rate(x2, cfg, codes, gi, "first64") > 0.45
+    assert 0.03 < R.predicted_redo_rate(x2, cfg, codes, gi) < 0.11
+    fam = R.input_families(seed=1, n_reads=2, read_len=64)
+    assert set(fam) == {"random", "lambda", "homopolymer", "dinucleotide", "trinucleotide", "n_rich"}
+    assert all(len(r) == 64 for v in fam.values() for r in v) and fam["n_rich"][-1] == "N" * 64

@@ -243,6 +243,22 @@ def test_native_fasta_parser_equals_the_line_loop(tmp_path, monkeypatch):
         p.write_text(text, encoding="latin-1", newline="")
         native, loop = both(str(p))
         assert native == loop, (name, native, loop)
+    # bytes the byte-level parser and the text-mode loop would read differently -- UTF-8 names (the loop decodes them),
+    # invalid UTF-8 (the loop raises), the separators 0x1c-0x1f and U+0085 (blanks for str.split), "\r\r\n" (two line ends) -- go to the loop
+    raw = {
+        "utf8_name.fastq": "@r\u00e9ad x\nAC\n+\nII\n".encode("utf-8"), "latin1_name.fastq": "@r\u00e9ad\nAC\n+\nII\n".encode("latin-1"),
+        "fs_sep.fastq": b"@a\x1cb\nAC\n+\nII\n", "nel_sep.fastq": "@a\u0085b\nAC\n+\nII\n".encode("utf-8"), "crcrlf.fastq": b"@a\nAC\r\r\n+\nII\n",
+        "utf8_name.fa": ">r\u00e9ad x\nAC\n".encode("utf-8"), "latin1_name.fa": ">r\u00e9ad\nAC\n".encode("latin-1"), "gs_sep.fa": b">a\x1db\nAC\n",
+        "us_in_seq.fa": b">a\n\x1fAC\x1f\nGT\n", "crcrlf.fa": b">a\nAC\r\r\nGT\n", "nbsp_seq.fa": ">a\n\u00a0AC\n".encode("utf-8"),
+    }
+    for name, data in raw.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        assert U._read_fasta_native(str(p)) is None, name
+        native, loop = both(str(p))
+        assert native == loop, (name, native, loop)
+    assert list(U.read_fasta(str(tmp_path / "utf8_name.fastq"))) == [("AC", "r\u00e9ad")]
+    assert list(U.read_fasta(str(tmp_path / "fs_sep.fastq"))) == [("AC", "a")]
     assert U._read_fasta_native(str(tmp_path / "fq_plain.fastq")) == [("ACGT", "q1"), ("acgtn", "q2")]
     assert U._read_fasta_native(str(tmp_path / "fq_no_plus.fastq")) is None
     for it in range(20):

@@ -6,7 +6,8 @@
 Every buffer handed to the library is malloc()ed at its exact size (so an off-by-one lands in a red zone) and every result is
 checked against an independent implementation: s2s_blow5_pack methods 0 / 1 / 3 (zlib.decompress; 2 = zstd when libzstd loads)
 and s2s_compress_rows, s2s_fasta_count / s2s_fasta_clean / s2s_fastq_clean against the line loop of utils.read_fasta,
-s2s_sampler_replay_law against utils.sampling_iter for the three length laws, s2s_length_law against scipy."""
+s2s_sampler_replay_law against utils.sampling_iter for the three length laws, s2s_length_law against scipy, s2s_copy_ranges /
+s2s_blow5_scan (the shard merge's helpers) against slices of the source files."""
 import ctypes as C
 import os
 import random
@@ -197,7 +198,7 @@ def native_parse(data: bytes, fastq, map_acgtn=0):
     return recs
 
 
-ALPHA = list("ACGTNacgtRY>@+ \t\r\n\n\n;I!")
+ALPHA = list("ACGTNacgtRY>@+ \t\r\n\n\n;I!") + ["\x1c", "\x1f", "\x85", "\xa0", "\xe9"]     # (the last five: the parser must hand the file back)
 
 
 def check_parsers():
@@ -224,6 +225,7 @@ def check_parsers():
         first = next((ln for ln in text.replace("\r\n", "\n").replace("\r", "\n").split("\n") if ln), "")
         if got is None:
             continue                                            # handed back to the line loop: nothing to compare
+        assert not any(ord(ch) >= 0x80 or 0x1c <= ord(ch) <= 0x1f for ch in text), ("parsed a file with bytes the line loop reads differently", text)
         if not fastq and first.startswith("@"):
             continue
         assert got == want, (fastq, text, got, want)
@@ -275,8 +277,60 @@ def check_laws():
         assert L.s2s_length_law(law, seed, 5000.0, 48502) == int(U.draw_length(name, 5000, seed, 48502))
 
 
+L.s2s_copy_ranges.restype = i64
+L.s2s_copy_ranges.argtypes = [i32, vp, vp, vp, vp, vp, i32]
+L.s2s_blow5_scan.restype = i64
+L.s2s_blow5_scan.argtypes = [i32, i64, i64]
+
+
+def check_merge_helpers(threads):
+    """s2s_copy_ranges: random non-overlapping destination ranges from two source files, on `threads` threads; s2s_blow5_scan: a
+    chain of [u64 size][body] records, whole and damaged."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        srcs = []
+        for i in range(2):
+            data = rng.integers(0, 256, int(rng.integers(1, 300000)), dtype=np.uint8).tobytes()
+            with open(os.path.join(td, f"s{i}"), "wb") as f:
+                f.write(data)
+            srcs.append((os.open(os.path.join(td, f"s{i}"), os.O_RDONLY), data))
+        n = int(rng.integers(0, 12))
+        jobs, at, want = [], 0, bytearray()
+        for _ in range(n):
+            k = int(rng.integers(0, 2))
+            fd, data = srcs[k]
+            so = int(rng.integers(0, len(data)))
+            ln = int(rng.integers(0, len(data) - so + 1))
+            gap = int(rng.integers(0, 9))
+            want += bytes(gap) + data[so:so + ln]
+            jobs.append((fd, so, at + gap, ln))
+            at += gap + ln
+        dst = os.open(os.path.join(td, "d"), os.O_RDWR | os.O_CREAT)
+        os.ftruncate(dst, at)
+        cols = [Buf(np.array([j[i] for j in jobs], dt).tobytes()) for i, dt in ((0, np.int32), (1, np.int64), (2, np.int64), (3, np.int64))]
+        dfd = Buf(np.full(n, dst, np.int32).tobytes())
+        got = L.s2s_copy_ranges(n, cols[0].p, cols[1].p, dfd.p, cols[2].p, cols[3].p, threads)
+        assert got == sum(j[3] for j in jobs), got
+        assert os.pread(dst, at, 0) == bytes(want)
+        for b in cols + [dfd]:
+            b.free()
+        # record chain
+        sizes = [int(rng.integers(0, 500)) for _ in range(int(rng.integers(0, 20)))]
+        chain = b"".join(struct.pack("<Q", z) + bytes(z) for z in sizes)
+        with open(os.path.join(td, "c"), "wb") as f:
+            f.write(b"HEAD" + chain + b"5WOLB")
+        cfd = os.open(os.path.join(td, "c"), os.O_RDONLY)
+        assert L.s2s_blow5_scan(cfd, 4, 4 + len(chain)) == len(sizes)
+        if chain:
+            assert L.s2s_blow5_scan(cfd, 4, 4 + len(chain) - 1) == -2          # the last record runs past the end
+        assert L.s2s_blow5_scan(cfd, 4, 3) < 0 and L.s2s_blow5_scan(-1, 0, 0) < 0
+        for fd in [x[0] for x in srcs] + [dst, cfd]:
+            os.close(fd)
+
+
 for it in range(rounds):
     check_pack(threads=[1, 2, 4, 8][it % 4])
+    check_merge_helpers(threads=[1, 3, 8][it % 3])
     for _ in range(8):
         check_parsers()
     if it % 3 == 0:

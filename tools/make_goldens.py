@@ -472,10 +472,72 @@ def pod5_goldens():
     np.savez_compressed(os.path.join(OUT, "pod5_records.npz"), **out)
 
 
+def mixed16_goldens():
+    """What the reference's OWN GPU arithmetic gives for the golden chunks: inference.py:403-404 selects precision "16-mixed" whenever a
+    GPU is present, i.e. Lightning runs predict_step under torch.autocast(device, dtype=torch.float16).  No GPU build of the
+    reference can run here, so the same predict_step (same committed checkpoints, same injected variates as y_gamma_nsamp) runs
+    under torch.autocast("cpu", dtype=torch.float16): the CPU autocast policy casts the same Linear / matmul / bmm inputs to
+    fp16 and keeps softmax / layer_norm in fp32 as the CUDA policy does; accumulation order differs from a GPU's, which is noise
+    two orders below the fp16 rounding this measures.  -> tests/golden/mixed16.npz: per checkpoint the 16-mixed signal rows, the
+    dwell indices under 16-mixed, and its MAE / max distance to the fp32 golden -- the bar the engine's opt-in reduced-precision
+    mode (S2S_MODE_F16) is held to (tests/test_gpu_parity.py: test_reduced_precision_f16_mode)."""
+    out = {}
+    for tag in ("k9", "k6"):
+        ck = torch.load(os.path.join(OUT, f"synthetic_{tag}.ckpt"), map_location="cpu", weights_only=True)
+        cfg = ck["hyper_parameters"]["config"]
+        m = RM.seq2squiggle(config=cfg)
+        m.load_state_dict(ck["state_dict"])
+        m.eval()
+        g = dict(np.load(os.path.join(OUT, f"stages_{tag}.npz")))
+        codes = g["codes"]
+        x = np.zeros(codes.shape + (5,), np.float16)
+        known = codes < 5
+        x[known] = np.eye(5, dtype=np.float16)[codes[known]]
+        x16 = torch.from_numpy(x)
+        names = [str(n) for n in g["names"]]
+        B = len(names)
+        sg = torch.from_numpy(g["sg"]).reshape(B, 16, 1)
+        z250 = torch.from_numpy(g["z01"])
+        common = dict(dwell_mean=12.5, dwell_std=0.0, min_duration=3)
+        with Inject(sg=sg, z_normal=[z250]):                 # sanity: the fp32 run reproduces the committed golden bit for bit
+            y32 = run_predict_step(m, names, x16, noise_std=2.0, noise_sampling=True, duration_sampling=True, min_noise=0.0, **common)
+        assert np.array_equal(y32.numpy(), g["y_gamma_nsamp"]), tag
+        with torch.autocast("cpu", dtype=torch.float16):
+            with Inject(sg=sg, z_normal=[z250]):
+                y16 = run_predict_step(m, names, x16, noise_std=2.0, noise_sampling=True, duration_sampling=True, min_noise=0.0,
+                                       **common).float()
+            enc_out, emb_out = m.encoders(x16.reshape(B, 16, -1))
+            sigma = m.noise_sampler(emb_out)
+            with Inject(sg=sg):
+                _, dpo, _, _, _ = m.length_regulator(emb_out=emb_out, x=enc_out, target=None, noise_std_prediction=sigma[:, :, None],
+                                                     max_length=250, dwell_mean=12.5, dwell_std=0.0, duration_sampling=True, min_length=3)
+        d = (y16 - y32).abs()
+        same = (y16 == 0) == (y32 == 0)
+        out[f"y_gamma_nsamp_16mixed_{tag}"] = y16.numpy()
+        out[f"dur_gamma_16mixed_{tag}"] = torch.round(dpo.float()).int().numpy()
+        out[f"mae_vs_fp32_{tag}"] = np.float64(d.mean())
+        out[f"max_vs_fp32_{tag}"] = np.float64(d.max())
+        out[f"zero_pattern_equal_share_{tag}"] = np.float64(same.float().mean())
+        # a dwell index that rounds the other way under fp16 shifts every later sample of its chunk: the distance on the chunks
+        # whose indices all agree is the arithmetic's own
+        agree = torch.from_numpy((out[f"dur_gamma_16mixed_{tag}"] == g["dur_gamma"]).all(1))
+        out[f"dwell_indices_differing_{tag}"] = np.int64((out[f"dur_gamma_16mixed_{tag}"] != g["dur_gamma"]).sum())
+        out[f"mae_vs_fp32_where_dwell_equal_{tag}"] = np.float64(d[agree].mean())
+        out[f"max_vs_fp32_where_dwell_equal_{tag}"] = np.float64(d[agree].max())
+        print(tag, "dwell indices differing:", int(out[f"dwell_indices_differing_{tag}"]), "of", g["dur_gamma"].size, "| on the", int(agree.sum()),
+              "chunks whose indices agree: MAE", float(d[agree].mean()), "max", float(d[agree].max()))
+        print(tag, "16-mixed vs fp32 golden: MAE", float(d.mean()), "max", float(d.max()), "zero pattern equal", float(same.float().mean()),
+              "dwell indices equal", bool(np.array_equal(out[f"dur_gamma_16mixed_{tag}"], g["dur_gamma"])))
+    np.savez_compressed(os.path.join(OUT, "mixed16.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["pod5"]:          # only the POD5 record goldens (they read the committed signals_*.npz)
         pod5_goldens()
+        return
+    if sys.argv[1:] == ["mixed16"]:       # only the reference-under-fp16-autocast vectors (they read the committed checkpoints and stages_*.npz)
+        mixed16_goldens()
         return
     sampler_goldens()
     chunker_goldens()
@@ -491,6 +553,7 @@ def main():
     pe = {"enc": RM.Encoder(base_config(9)).position_enc.numpy(), "dec": RM.Decoder(base_config(9)).position_enc.numpy()}
     np.savez_compressed(os.path.join(OUT, "position_enc.npz"), **pe)
     pod5_goldens()
+    mixed16_goldens()
     print("goldens written to", OUT)
 
 

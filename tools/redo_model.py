@@ -1,60 +1,36 @@
 #!/usr/bin/env python
-"""CPU model of the fast softmax path's redo rate (no GPU): for several decoder weights, the share of (wave, head, layer) softmax
-runs in which some row's largest score beats the maximum over the PASS-0 KEY SET by more than the f16 range allows (18 log2
-units with the 2-unit head-room) -- under different choices of that key set.  The oracle supplies the decoder's scores.  It
-reproduces the redo rates the kernel's counters report (x 2: 0.55 / 0.59 measured, positional 2 I: 0.093 / 0.104) and is what the
-key order of the K / V^T images (s2s_device_h.h: att32_key_at) was chosen with."""
-import sys, os, math
+"""CPU model of the fast softmax path's redo rate (no GPU; oracle/redo_model.py) for several decoder weights under different
+choices of the pass-0 key set.  It reproduces the redo rates the kernel's counters report (x 2 with the first 64 keys: 0.55 model /
+0.59 measured; positional 2 I: 0.093 / 0.104) and is what the key order of the K / V^T images (s2s_device_h.h: att32_key_at) was
+chosen with."""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch, torch.nn.functional as F
-from oracle import s2s_oracle as O
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from oracle import redo_model as R
 import seq2squiggle_amd as S
+
 torch.set_float32_matmul_precision("highest")
-sd0, cfg = S.load_checkpoint(os.path.join(ROOT, 'tests', 'golden', 'synthetic_k9.ckpt'))
-g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'stages_k9.npz')))
-codes = g['codes'][:48]
+sd0, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
+g = dict(np.load(os.path.join(ROOT, "tests", "golden", "stages_k9.npz")))
+codes, inj = g["codes"][:48], torch.from_numpy(g["g"][:48])
+QK = ("w_qs.weight", "w_ks.weight", "w_qs.bias", "w_ks.bias")
+
+
 def variants():
     for sc in (1.0, 2.0, 4.0, 16.0):
-        sd = {k: v.clone() for k, v in sd0.items()}
-        for k in sd:
-            if k.startswith("decoders.") and k.endswith(("w_qs.weight","w_ks.weight","w_qs.bias","w_ks.bias")): sd[k] *= sc
-        yield f"committed x{sc:g}", sd
+        yield f"committed x{sc:g}", {k: (v * sc if k.startswith("decoders.") and k.endswith(QK) else v.clone()) for k, v in sd0.items()}
     for c in (2.0, 3.0, 5.0):
         sd = {k: v.clone() for k, v in sd0.items()}
         for k in sd:
-            if k.startswith("decoders.") and k.endswith(("w_qs.weight","w_ks.weight","w_qs.bias","w_ks.bias")):
-                sd[k] = c*torch.eye(64) if k.endswith("weight") else torch.zeros(64)
+            if k.startswith("decoders.") and k.endswith(QK):
+                sd[k] = c * torch.eye(64) if k.endswith("weight") else torch.zeros(64)
         yield f"positional {c:g} I", sd
-keys = np.arange(250)
-schemes = {
-  "first 64 keys (rounds 1-3)": keys < 64,
-  "blocks of 4, every 4th block (HEAD)": ((keys >> 2) & 3) == 0,
-  "every 4th key": (keys & 3) == 0,
-}
+
+
 for name, sd in variants():
-    p = O.PredictParams(noise_std=0.0)
-    gen = torch.Generator().manual_seed(1)
-    out = O.predict_chunks(sd, cfg, codes, p, inject_g=torch.from_numpy(g['g'][:48]), stages=True)
-    h = out['lr_out'] + sd["decoders.position_enc"][0]
-    res = {k: [0, 0] for k in list(schemes) + ["first 64 + own 32-key tile"]}
-    for l in range(cfg["decoder_layers"]):
-        pfx = f"decoders.layer_stack_FFT.{l}.slf_attn."
-        B, T, D = h.shape
-        q = F.linear(h, sd[pfx+"w_qs.weight"], sd[pfx+"w_qs.bias"]).view(B, T, 8, 8).permute(0,2,1,3)
-        k = F.linear(h, sd[pfx+"w_ks.weight"], sd[pfx+"w_ks.bias"]).view(B, T, 8, 8).permute(0,2,1,3)
-        s = (q @ k.transpose(-1,-2)) / math.sqrt(8) * math.log2(math.e)       # [B, head, query, key], log2 units
-        full = s.max(-1).values
-        for sname, mask in schemes.items():
-            m0 = s[..., torch.from_numpy(mask)].max(-1).values
-            over = (full - m0) > 18.0                                         # this row's P_hi overflows
-            # a (wave, head) run is redone when any of its 32 queries overflows
-            pad = F.pad(over, (0, 6)).view(B, 8, 8, 32).any(-1)
-            res[sname][0] += int(pad.sum()); res[sname][1] += pad.numel()
-        m0 = s[..., :64].max(-1).values
-        own = torch.stack([s[:, :, t, (t//32)*32:min(250,(t//32)*32+32)].max(-1).values for t in range(250)], -1)
-        over = (full - torch.maximum(m0, own)) > 18.0
-        pad = F.pad(over, (0, 6)).view(B, 8, 8, 32).any(-1)
-        res["first 64 + own 32-key tile"][0] += int(pad.sum()); res["first 64 + own 32-key tile"][1] += pad.numel()
-        h = O.fft_block(sd, f"decoders.layer_stack_FFT.{l}.", h, 8)
-    print(name, {k: f"{v[0]/v[1]:.4f}" for k, v in res.items()})
+    print(name, {s: f"{R.predicted_redo_rate(sd, cfg, codes, inj, s):.4f}" for s in R.SCHEMES})
