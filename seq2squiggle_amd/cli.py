@@ -206,6 +206,13 @@ def _launch_ranks(gpus: int):
     procs = [subprocess.Popen(cmd, env=dict(base, **rank_env(r))) for r in range(gpus)]
     rc = 0
     try:
+        try:                                    # the merge's imports (numpy, pyarrow, the library) load while the ranks work
+            from . import merge, pod5_io, signal_io  # noqa: F401
+            pod5_io._pa()
+            from ._lib import lib
+            lib()
+        except Exception:                       # (reported by the merge itself, if it comes to that)
+            pass
         left = set(range(gpus))
         while left:
             for r in sorted(left):

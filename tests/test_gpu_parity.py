@@ -325,7 +325,7 @@ def test_attention_path_calibration_and_overrides(monkeypatch):
         eng.close()
     for env in ("sideways", "e", "1", "exactly"):                 # a typo must not pin a path silently
         monkeypatch.setenv("S2S_ATTENTION_PATH", env)
-        with pytest.raises(RuntimeError, match="S2S_ATTENTION_PATH"):
+        with pytest.raises(ValueError, match="S2S_ATTENTION_PATH must be fast, exact or auto"):
             S.Engine(sd, cfg, mode="f16x3")
     monkeypatch.delenv("S2S_ATTENTION_PATH")
     eng = S.Engine(sharp, cfg, mode="f32")                        # the f32 block has one softmax path

@@ -2,8 +2,9 @@
 # Rehearsal of the N > 1 paths at the largest rank count the GPU pool allows on ONE device (its process guard kills a run with
 # more than 6 GPU processes, the launcher counts as one: 5 ranks, not 8): bench.py --gpus N and `predict --gpus N` with every rank on cuda:0.
 # THIS IS NOT A SCALING MEASUREMENT -- the ranks share one GPU; it exercises what an 8-GPU node exercises on the host:
-# N children under torch.distributed.run, cpu_share() = quota / LOCAL_WORLD_SIZE threads per rank, N shard files at once,
-# the gloo barriers of the sharded leg, the N-way merge.       tools/rehearse_ranks.sh [N=5] [out_dir]
+# N child ranks (bench: under torch.distributed.run; predict --gpus N: started directly by the CLI), cpu_share() = quota /
+# LOCAL_WORLD_SIZE threads per rank, N shard files at once, the gloo barriers of the sharded leg, the N-way byte-range merge
+# (the CLI prints its launch / ranks / merge seconds).       tools/rehearse_ranks.sh [N=5] [out_dir]
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 N=${1:-5}; out=${2:-gpurun_out/rehearsal}; mkdir -p $out
 echo "NOT A SCALING MEASUREMENT: $N ranks on ONE GPU (host-side rehearsal of the multi-GPU paths)" | tee $out/README.txt
@@ -12,7 +13,7 @@ python - $out/bench_${N}ranks_one_gpu.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 s = d.get("end_to_end_sharded", {})
-print("bench: n_ranks_seen", d["n_ranks_seen"], "| sharded leg:", {k: s.get(k) for k in ("seconds", "chunks_per_sec", "per_rank_seconds", "per_rank_cpu_share_threads", "error", "skipped")})
+print("bench: n_ranks_seen", d["n_ranks_seen"], "| sharded leg:", {k: s.get(k) for k in ("seconds", "chunks_per_sec", "per_rank_seconds", "per_rank_cpu_share_threads", "merge_seconds", "merge", "with_merge", "one_command", "error", "skipped")})
 PY
 # 1/8-scale BASELINE configs[4]: a 12.5 Mb synthetic reference (one GPU's share of the 100 Mb job), -c 30 -r 10000 -> .pod5, N ranks, merged
 tmp=$(mktemp -d -p ${S2S_REHEARSE_TMP:-/tmp}); trap "rm -rf $tmp" EXIT
@@ -30,5 +31,5 @@ same = len(a) == len(b) and all(np.array_equal(x["signal"], y["signal"]) and x["
 print(f"predict --gpus {sys.argv[3]} (one GPU) -> merged .pod5: {len(a)} reads, {os.path.getsize(sys.argv[1])} bytes; single process: {len(b)} reads; per-read samples and numbering equal: {same}")
 sys.exit(0 if same else 1)
 PY
-grep -E "real|reads from|ranks" $out/predict_${N}ranks_one_gpu.log | tail -5 | tee -a $out/README.txt
+grep -E "real|reads from" $out/predict_${N}ranks_one_gpu.log | tail -5 | tee -a $out/README.txt
 grep -E "real" $out/predict_single.log | tail -2 | sed 's/^/single process: /' | tee -a $out/README.txt
