@@ -420,15 +420,14 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
         merged, command = None, None
         if rank == 0 and not errs:
             # the ONE file the reference leaves (inference.py:65-79): rank 0 joins the rank files while the others wait -- as the
-            # parent of `predict --gpus N` does once its ranks have exited, with the whole CPU quota for its copy threads
+            # parent of `predict --gpus N` does once its ranks have exited
             try:
                 from seq2squiggle_amd.parallel import rank_output_path
                 from seq2squiggle_amd.signal_io import merge_shards
                 shards = [rank_output_path(os.path.join(rows[r][6], "o.blow5"), r, world) for r in range(world)]
-                threads = max(1, cpu_share() * int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
                 t1 = time.perf_counter()
-                n_rec = merge_shards(shards, os.path.join(td, "merged.blow5"), threads=threads, consume=True)
-                merged = dict(merge_shards.last, seconds=time.perf_counter() - t1, records=n_rec, threads=threads)
+                n_rec = merge_shards(shards, os.path.join(td, "merged.blow5"), consume=True)
+                merged = dict(merge_shards.last, seconds=time.perf_counter() - t1, records=n_rec)
             except Exception as e:
                 merged = {"error": f"{type(e).__name__}: {e}"}
             shutil.rmtree(td, ignore_errors=True)              # (room for the command below)
@@ -456,8 +455,9 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
         out["merge_seconds"] = merged["seconds"]
         out["merge"] = {"bytes": merged.get("bytes"), "bytes_copied": merged.get("bytes_copied"), "threads": merged["threads"],
                         "gb_per_sec": merged.get("bytes", 0) / merged["seconds"] / 1e9, "records": merged["records"],
-                        "how": "first rank file becomes the output, the record sections of the others move as byte ranges "
-                               "(copy_file_range on native threads, seq2squiggle_amd/merge.py)"}
+                        "remove_seconds": merged.get("remove_seconds"),
+                        "how": "first rank file becomes the output, the record sections of the others move as byte ranges (copy_file_range, "
+                               "one writer: seq2squiggle_amd/merge.py), each rank file deleted as soon as it is in"}
         out["with_merge"] = {"seconds": wall + merged["seconds"], "chunks_per_sec": total / (wall + merged["seconds"]),
                              "reads_per_sec": n_total / (wall + merged["seconds"])}
     elif merged:

@@ -278,7 +278,9 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
  * leaves ONE output file (inference.py:65-79, signal_io.py:167-171, 268-282), a sharded run one per rank.
  * s2s_copy_ranges copies n byte ranges (src_fd[i], src_off[i], len[i]) -> (dst_fd[i], dst_off[i]) on `threads` threads with
  * copy_file_range (in the kernel, no user-space buffer; pread / pwrite through a bounce buffer where the file system refuses it);
- * ranges must not overlap inside one file.  Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the failing call).
+ * ranges must not overlap inside one file.  One destination file has one fast writer (the inode lock; measured in
+ * profiles/r05/fs_write_probe_shm.txt: 6.5 GB/s with one writer, 3.2-4.1 GB/s with 2-8), so pass threads = 1 per destination.
+ * Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the failing call).
  * s2s_blow5_scan walks the [u64 size][body] records of a BLOW5 file between byte offsets begin and end (the end of the
  * header and the start of the end-of-file marker) reading the size prefixes only: the record count, or -2 when the chain of
  * sizes does not end exactly at `end` (a truncated shard). */

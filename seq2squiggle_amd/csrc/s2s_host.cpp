@@ -907,10 +907,6 @@ extern "C" int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_a
 // descriptors; nothing passes through the interpreter or (copy_file_range) through user space.
 #include <cerrno>
 #include <fcntl.h>
-#include <map>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <sys/statvfs.h>
 #include <unistd.h>
 
 namespace {
@@ -942,37 +938,19 @@ int64_t copy_one(int src, int64_t src_off, int dst, int64_t dst_off, int64_t len
 
 }  // namespace
 
-// Writers of ONE file take its inode lock in turn (generic_file_write_iter; tmpfs, ext4 and XFS alike for buffered writes), so N
-// threads of pwrite / copy_file_range into the merged file run one after the other: 2.1 GB/s with 15 threads on the GPU box's
-// tmpfs, the speed of one.  Stores through a shared mapping take no such lock -- a page fault allocates the page, the copy is
-// a memcpy -- so the ranges are copied between mappings of the files, and the threads scale with the memory system.  The
-// mapping path needs the space to exist (a full file system would raise SIGBUS instead of ENOSPC): it is used only when the
-// destination's file system reports the room (fstatvfs), else -- and for anything mmap refuses -- the descriptor path runs.
-namespace {
-struct Mapping { void* base = MAP_FAILED; size_t size = 0; };
-
-bool map_files(const std::vector<int>& fds, bool writable, std::map<int, Mapping>& out) {
-    for (int fd : fds) {
-        if (out.count(fd)) continue;
-        struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return false;
-        Mapping m;
-        m.size = (size_t)st.st_size;
-        m.base = mmap(nullptr, m.size, writable ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, fd, 0);
-        if (m.base == MAP_FAILED) return false;
-        out[fd] = m;
-    }
-    return true;
-}
-}  // namespace
-
+// One destination file has ONE fast writer: buffered writes (pwrite, copy_file_range) take its inode lock, and stores through a
+// shared mapping -- which take no such lock -- fill the page cache no faster (the page allocation is the bound).  Measured on the
+// MI355X box's host (profiles/r05/fs_write_probe_*.txt, merge_bench_*_mapped_vs_fd.txt): one writer fills a tmpfs file at 6.5 GB/s,
+// 2-8 concurrent writers of the SAME file at 3.2-4.1 GB/s, a mapped copy at 3.0-4.5 GB/s with 1-16 threads; separate files scale
+// (42 GB/s with 8 writers).  So `threads` is the caller's knob (seq2squiggle_amd/merge.py passes 1 per destination), not a default
+// to raise; the mapped engine of commit 1b15c95 was dropped.
 extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd,
                                    const int64_t* dst_off, const int64_t* len, int32_t threads) {
     if (n < 0 || threads < 1 || (n > 0 && (!src_fd || !src_off || !dst_fd || !dst_off || !len))) return S2S_ERR_ARG;
-    // pieces of <= 32 MiB, so that one long range does not leave the other threads idle
+    // pieces of <= 64 MiB, so that one long range does not leave the other threads (when asked for) idle
     struct Piece { int src, dst; int64_t so, d_o, len; };
     std::vector<Piece> pieces;
-    const int64_t cut = 32ll << 20;
+    const int64_t cut = 64ll << 20;
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (len[i] < 0 || src_off[i] < 0 || dst_off[i] < 0) return S2S_ERR_ARG;
@@ -980,26 +958,8 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
             pieces.push_back({src_fd[i], dst_fd[i], src_off[i] + o, dst_off[i] + o, std::min(cut, len[i] - o)});
         total += len[i];
     }
-    if (pieces.empty()) return 0;
-    // ---- through mappings, when every file maps, holds its ranges, and the destination's file system has the room
-    std::map<int, Mapping> srcs, dsts;
-    const char* how = getenv("S2S_COPY_RANGES");                    // "fd": descriptor path only (A/B, tests)
-    bool mapped = !(how && how[0] == 'f');
-    if (mapped) {
-        std::vector<int> s_fds, d_fds;
-        for (const Piece& p : pieces) { s_fds.push_back(p.src); d_fds.push_back(p.dst); }
-        for (int fd : d_fds) {
-            struct statvfs vf;
-            if (fstatvfs(fd, &vf) != 0 || (double)vf.f_bavail * (double)vf.f_frsize < 1.02 * (double)total + (64 << 20)) { mapped = false; break; }
-        }
-        mapped = mapped && map_files(s_fds, false, srcs) && map_files(d_fds, true, dsts);
-        if (mapped)
-            for (const Piece& p : pieces)
-                if ((size_t)(p.so + p.len) > srcs[p.src].size || (size_t)(p.d_o + p.len) > dsts[p.dst].size || srcs.count(p.dst)) { mapped = false; break; }
-    }
     std::atomic<size_t> next{0};
     std::atomic<int64_t> err{0};
-    [[maybe_unused]] const bool populate_ok = !(how && how[0] == 'm' && how[1] == '0');     // "m0": mapped copy without MADV_POPULATE_* (A/B)
     auto work = [&] {
         std::vector<uint8_t> bounce;
         bool in_kernel = true;
@@ -1007,21 +967,6 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
             const size_t i = next.fetch_add(1);
             if (i >= pieces.size() || err.load()) return;
             const Piece& p = pieces[i];
-            if (mapped) {
-                // whole piece faulted in by two calls instead of one trap per 4-KiB page (Linux 5.14+; refused elsewhere: plain faults)
-                auto populate = [](uint8_t* at, int64_t bytes, int advice) {
-                    const uintptr_t lo = (uintptr_t)at & ~(uintptr_t)4095, hi = ((uintptr_t)at + (uintptr_t)bytes + 4095) & ~(uintptr_t)4095;
-                    (void)madvise((void*)lo, hi - lo, advice);
-                };
-#ifdef MADV_POPULATE_WRITE
-                if (populate_ok) {
-                    populate(static_cast<uint8_t*>(srcs[p.src].base) + p.so, p.len, MADV_POPULATE_READ);
-                    populate(static_cast<uint8_t*>(dsts[p.dst].base) + p.d_o, p.len, MADV_POPULATE_WRITE);
-                }
-#endif
-                std::memcpy(static_cast<uint8_t*>(dsts[p.dst].base) + p.d_o, static_cast<const uint8_t*>(srcs[p.src].base) + p.so, (size_t)p.len);
-                continue;
-            }
             const int64_t r = copy_one(p.src, p.so, p.dst, p.d_o, p.len, bounce, in_kernel);
             if (r < 0) err = r;
         }
@@ -1031,8 +976,6 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
     for (int w = 1; w < workers; ++w) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
-    for (auto& m : srcs) munmap(m.second.base, m.second.size);
-    for (auto& m : dsts) munmap(m.second.base, m.second.size);
     return err.load() < 0 ? err.load() : total;
 }
 

@@ -2,11 +2,18 @@
 leaves (inference.py:65-79; signal_io.py:167-171, 268-282) without re-reading a record in the interpreter.
 
 A shard's payload -- the BLOW5 record section, the lines of a SLOW5 file, the buffers of a POD5 signal table -- is a handful of
-byte ranges whose place in the merged file follows from prefix sums, so the merge is: lay out, then copy every range with
-copy_file_range from several threads (s2s_copy_ranges in libs2s_hip.so: in the kernel, no user-space buffer), then write the few
-KB that are new (BLOW5: the end marker; POD5: batch metadata, the reads table, the footers -- pod5_io.merge_pod5).
-`take_first=True` turns the first shard INTO the output file (its payload is already where it belongs), so only the other
-shards' bytes move; the shard files are consumed then."""
+byte ranges whose place in the merged file follows from prefix sums, so the merge is: lay out, copy every range with
+copy_file_range (s2s_copy_ranges in libs2s_hip.so: in the kernel, no user-space buffer), then write the few KB that are new
+(BLOW5: the end marker; POD5: batch metadata, the reads table, the footers -- pod5_io.merge_pod5).
+
+What bounds it is the file system, not this code: ONE destination file is filled by ONE writer at a time (the inode lock), at
+4.7-6.6 GB/s on the MI355X box's tmpfs and 6.5-11 GB/s into its page cache; more writers of the same file are SLOWER there
+(3.2-4.1 GB/s), while separate files scale to 42 GB/s (profiles/r05/fs_write_probe_*.txt) -- which is why the ranks write
+their own files and the join is one sequential pass.  Hence one copy thread by default.
+`take_first=True` turns the first shard INTO the output file (its payload is already where it belongs: 1/N fewer bytes move);
+`consume=True` deletes every other shard as soon as its bytes are in the output, on a helper thread beside the copy of the
+next one (freeing 6 GB of tmpfs pages takes 0.5 s, and the pages go straight back to the copy: the peak is the output + one shard,
+not twice the output)."""
 import os
 import struct
 import time
@@ -19,9 +26,33 @@ BLOW5_EOF = b"5WOLB"
 
 
 def merge_threads() -> int:
-    """Copy threads of a merge: the CPU share of this process (signal_io.cpu_share), S2S_MERGE_THREADS overrides."""
-    from .signal_io import cpu_share
-    return max(1, int(os.environ.get("S2S_MERGE_THREADS", "0")) or min(32, cpu_share()))
+    """Copy threads per destination file: 1 (see the module text); S2S_MERGE_THREADS overrides."""
+    return max(1, int(os.environ.get("S2S_MERGE_THREADS", "0") or 0) or 1)
+
+
+class _Remover:
+    """consume=True: shard files are deleted, in order, by one helper thread while the copy of the next shard runs."""
+
+    def __init__(self, enabled: bool):
+        self.ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-unlink") if enabled else None
+        self.pending = []
+        self.seconds = 0.0
+
+    def remove(self, path: str) -> None:
+        if self.ex is not None:
+            self.pending.append(self.ex.submit(self._one, path))
+
+    def _one(self, path):
+        t = time.perf_counter()
+        os.remove(path)
+        self.seconds += time.perf_counter() - t
+
+    def finish(self) -> float:
+        for f in self.pending:
+            f.result()
+        if self.ex is not None:
+            self.ex.shutdown()
+        return self.seconds
 
 
 def copy_ranges(jobs: Sequence[Tuple[int, int, int, int, int]], threads: int = None) -> int:
@@ -119,21 +150,23 @@ def _scan_blow5(fd: int, begin: int, end: int, path: str) -> int:
     return n
 
 
-def merge_blow5(paths: Sequence[str], out: str, threads: int = None, take_first: bool = False) -> Tuple[int, dict]:
+def merge_blow5(paths: Sequence[str], out: str, threads: int = None, take_first: bool = False, consume: bool = False) -> Tuple[int, dict]:
     """BLOW5 shards with identical headers -> `out`: header of the first, every shard's record section at its prefix-sum offset,
     one end-of-file marker.  Nothing is decompressed or parsed beyond the u64 size prefixes (counted for the return value and
-    as the truncation check).  -> (records, {"bytes_copied", "seconds"})."""
+    as the truncation check; all shards are checked before the first byte moves).  -> (records, {"bytes_copied", "seconds", ...})."""
     t0 = time.perf_counter()
     threads = threads or merge_threads()
     same = lambda text: [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]   # the wall clock may differ
+    remover = _Remover(consume)
     with _Files() as files:
         fds = [files.open(p_) for p_ in paths]
         lay = [_blow5_layout(fd, p_) for fd, p_ in zip(fds, paths)]
         for p_, (head, text, _, _) in zip(paths[1:], lay[1:]):
             if head != lay[0][0] or same(text) != same(lay[0][1]):
                 raise ValueError(f"{p_}: header differs from {paths[0]} (another profile, compression or run?)")
-        with ThreadPoolExecutor(max_workers=min(threads, len(paths))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(paths))) as ex:       # (reads 8 bytes per record: not the destination's business)
             counts = list(ex.map(lambda i: _scan_blow5(fds[i], lay[i][2], lay[i][3], paths[i]), range(len(paths))))
+        t_scan = time.perf_counter() - t0
         sizes = [end - begin for _, _, begin, end in lay]
         at = np.concatenate([[lay[0][2]], lay[0][2] + np.cumsum(sizes)]).astype(np.int64)
         if take_first:
@@ -145,9 +178,16 @@ def merge_blow5(paths: Sequence[str], out: str, threads: int = None, take_first:
             os.pwrite(dst, lay[0][0] + struct.pack("<I", len(lay[0][1])) + lay[0][1], 0)
             first = 0
         os.ftruncate(dst, int(at[-1]) + len(BLOW5_EOF))
-        copied = copy_ranges([(fds[i], lay[i][2], dst, int(at[i]), sizes[i]) for i in range(first, len(paths))], threads)
+        copied = 0
+        for i in range(first, len(paths)):
+            copied += copy_ranges([(fds[i], lay[i][2], dst, int(at[i]), sizes[i])], threads)
+            os.close(fds[i])
+            files.fds.remove(fds[i])
+            remover.remove(paths[i])
         os.pwrite(dst, BLOW5_EOF, int(at[-1]))
-    return int(sum(counts)), {"bytes_copied": copied, "seconds": time.perf_counter() - t0}
+    removing = remover.finish()
+    return int(sum(counts)), {"bytes_copied": copied, "seconds": time.perf_counter() - t0, "scan_seconds": t_scan,
+                              "remove_seconds": removing, "threads": threads}
 
 
 def _slow5_header_end(fd: int, path: str) -> int:
@@ -197,6 +237,6 @@ def merge_slow5(paths: Sequence[str], out: str, threads: int = None) -> Tuple[in
             return n
         with ThreadPoolExecutor(max_workers=max(1, min(threads or merge_threads(), len(paths)))) as ex:
             counting = ex.map(lines, range(len(paths)))
-            copied = copy_ranges([(fds[i], begins[i], dst, int(at[i]), ends[i] - begins[i]) for i in range(len(paths))], threads)
+            copied = copy_ranges([(fds[i], begins[i], dst, int(at[i]), ends[i] - begins[i]) for i in range(len(paths))], threads or merge_threads())
             n = sum(counting)
     return int(n), {"bytes_copied": copied, "seconds": time.perf_counter() - t0}

@@ -15,7 +15,6 @@ Layout:  signature | marker | signal table | pad8 | marker | run-info table | pa
 """
 import datetime as _dt
 import io
-from concurrent.futures import ThreadPoolExecutor
 import struct
 import uuid
 from typing import Dict, List, Sequence
@@ -608,7 +607,9 @@ class _Shard:
     def close(self):
         import os
         self.buf = None        # (views handed out keep the map alive until they go)
-        os.close(self.fd)
+        if self.fd >= 0:
+            os.close(self.fd)
+            self.fd = -1
 
 
 def _signal_template(pa, schema, vbz: bool, k: int):
@@ -643,15 +644,16 @@ def _arrow_tail(pa, schema, blocks: np.ndarray) -> bytes:
 
 
 def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: bool = False, file_identifier=None,
-               section_marker: bytes = None) -> int:
+               section_marker: bytes = None, consume: bool = False) -> int:
     """POD5 shards written by this package (the out.rankN.pod5 files of a multi-process run) -> one file with the reads in the order
     given.  The signal table is re-batched WITHOUT touching a sample: every output batch of SIGNAL_BATCH_ROWS rows is a patched
     copy of pyarrow's own message metadata, the 16-byte ids / offsets / sample counts of its rows (3 KB, from the shards' memory
-    maps) and the rows' stored bytes, which are consecutive in their shard and move by copy_file_range on `threads` threads
-    (merge.copy_ranges).  Only the reads table (signal-row indices shifted by the rows of the earlier shards, dictionaries united;
+    maps) and the rows' stored bytes, which are consecutive in their shard and move by copy_file_range (merge.copy_ranges: one
+    writer, front to back).  Only the reads table (signal-row indices shifted by the rows of the earlier shards, dictionaries united;
     columnar, no per-read object), the run-info table and the two footers are built anew.  The result is byte for byte what
     Pod5FileWriter writes when it is handed all the reads in turn.  take_first: the first shard BECOMES the output (its full signal
-    batches stay where they are; the shard files are consumed).  -> number of reads; merge_pod5.last holds bytes / seconds."""
+    batches stay where they are); consume: every other shard is deleted once its rows are in.  -> number of reads;
+    merge_pod5.last holds bytes / seconds."""
     import os
     import time
     from . import merge as M
@@ -737,53 +739,92 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
         cols, run_ids, run_infos, pore_types = _merged_read_columns(pa, shards, n_rows)
         del per
 
-        with M._Files() as files, ThreadPoolExecutor(max_workers=1) as background:
+        # ---- the small parts of every batch that moves -- message metadata + ids + offsets in front of the data, sample counts behind
+        # it -- are laid back to back in a memory file, so that they are byte ranges like the rest and ONE writer fills the output
+        # front to back (merge.py: a second writer of the same file slows both down)
+        parts, part_jobs = bytearray(), []
+        for b in range(keep, n_batches):
+            lo, hi = b * R, min(b * R + R, n)
+            msg, m, bufs = tmpl[hi - lo]
+            part = bytearray(msg)
+            grow = _pad8(int(data_bytes[b])) - _pad8(int(bufs[di, 1]))
+            nb = bufs.copy()
+            nb[di, 1] = data_bytes[b]
+            nb[di + 1:, 0] += grow
+            part[m["buffers"][0]: m["buffers"][0] + nb.size * 8] = nb.tobytes()
+            struct.pack_into("<q", part, m["body_len"], int(body_len[b]))
+            if not vbz:                                                  # FieldNode of the list's child: its length is the sample count
+                struct.pack_into("<q", part, m["nodes"][0] + 16 * 2, int(data_units[b]))
+            o = m["meta"]
+            part[o + bufs[1, 0]: o + bufs[1, 0] + 16 * (hi - lo)] = ids[lo:hi].tobytes()
+            part[o + bufs[3, 0]: o + bufs[3, 0] + 8 * (hi - lo + 1)] = (cum[lo:hi + 1] - cum[lo]).astype("<i8").tobytes()
+            front = o + int(bufs[di, 0])
+            back = front + _pad8(int(bufs[di, 1]))                       # the template's data (one unit per row) is cut out
+            last = o + int(bufs[-1, 0])
+            part[last: last + 4 * (hi - lo)] = counts[lo:hi].astype("<u4").tobytes()
+            at = sig_start + int(msg_at[b])
+            behind = bytes(_pad8(int(data_bytes[b])) - int(data_bytes[b])) + bytes(part[back:])
+            part_jobs.append((len(parts), at, front))
+            parts += part[:front]
+            part_jobs.append((len(parts), at + front + int(data_bytes[b]), len(behind)))
+            parts += behind
+        end_of_batches = sig_start + int(msg_at[-1])
+        part_jobs.append((len(parts), end_of_batches, len(tail)))
+        parts += tail
+        for d, blob in stash:                                            # (take_first: shard 0's rows of the first batch that moves)
+            part_jobs.append((len(parts), d, len(blob)))
+            parts += blob
+
+        remover = M._Remover(consume)
+        with M._Files() as files:
             if take_first:
                 os.replace(paths[0], out)
                 fd = files.open(out, os.O_RDWR)
             else:
                 fd = files.open(out, os.O_RDWR | os.O_CREAT | os.O_EXCL)
                 os.pwrite(fd, SIGNATURE + marker + head, 0)
-            end_of_batches = sig_start + int(msg_at[-1])
-            os.ftruncate(fd, max(end_of_batches, os.fstat(fd).st_size))       # (grown at once; cut to its final size below)
-            jobs = [(shards[int(shard_of[i])].fd, int(pos[i]), fd, int(dst[i]), int(nb))
-                    for i, nb in zip(run[moving], run_bytes[moving]) if not (take_first and shard_of[i] == 0)]
-            copying = background.submit(M.copy_ranges, jobs, threads)
-            # the small parts of every batch that moves: message metadata + ids + offsets in front of the data, sample counts behind
-            for b in range(keep, n_batches):
-                lo, hi = b * R, min(b * R + R, n)
-                msg, m, bufs = tmpl[hi - lo]
-                part = bytearray(msg)
-                grow = _pad8(int(data_bytes[b])) - _pad8(int(bufs[di, 1]))
-                nb = bufs.copy()
-                nb[di, 1] = data_bytes[b]
-                nb[di + 1:, 0] += grow
-                part[m["buffers"][0]: m["buffers"][0] + nb.size * 8] = nb.tobytes()
-                struct.pack_into("<q", part, m["body_len"], int(body_len[b]))
-                if not vbz:                                                  # FieldNode of the list's child: its length is the sample count
-                    struct.pack_into("<q", part, m["nodes"][0] + 16 * 2, int(data_units[b]))
-                o = m["meta"]
-                part[o + bufs[1, 0]: o + bufs[1, 0] + 16 * (hi - lo)] = ids[lo:hi].tobytes()
-                part[o + bufs[3, 0]: o + bufs[3, 0] + 8 * (hi - lo + 1)] = (cum[lo:hi + 1] - cum[lo]).astype("<i8").tobytes()
-                front = o + int(bufs[di, 0])
-                back = front + _pad8(int(bufs[di, 1]))                       # the template's data (one unit per row) is cut out
-                last = o + int(bufs[-1, 0])
-                part[last: last + 4 * (hi - lo)] = counts[lo:hi].astype("<u4").tobytes()
-                at = sig_start + int(msg_at[b])
-                os.pwrite(fd, bytes(part[:front]), at)
-                os.pwrite(fd, bytes(_pad8(int(data_bytes[b])) - int(data_bytes[b])) + bytes(part[back:]), at + front + int(data_bytes[b]))
-            copied = copying.result()
-            for d, blob in stash:
-                os.pwrite(fd, blob, d)
-            os.pwrite(fd, tail, end_of_batches)
-
+            os.ftruncate(fd, max(end_of_batches + len(tail), os.fstat(fd).st_size))     # (grown at once; cut to its final size below)
+            try:
+                pfd = os.memfd_create("s2s-merge-parts")
+            except (AttributeError, OSError):
+                import tempfile
+                tf = tempfile.TemporaryFile()
+                pfd = os.dup(tf.fileno())
+                tf.close()
+            files.fds.append(pfd)
+            os.pwrite(pfd, bytes(parts), 0)
+            # every job, in the order of the output; a shard is closed and (consume) deleted once its last range is in
+            jobs = [(pfd, so, fd, d, ln, -1) for so, d, ln in part_jobs]
+            jobs += [(shards[int(shard_of[i])].fd, int(pos[i]), fd, int(dst[i]), int(nb), int(shard_of[i]))
+                     for i, nb in zip(run[moving], run_bytes[moving]) if not (take_first and shard_of[i] == 0)]
+            jobs.sort(key=lambda j_: j_[3])
+            last_job_of = {}
+            for k_, j_ in enumerate(jobs):
+                if j_[5] >= 0:
+                    last_job_of[j_[5]] = k_
+            cut_after = sorted((k_, s_i) for s_i, k_ in last_job_of.items())
+            copied, start = 0, 0
+            done_shards = set()
+            for k_, s_i in cut_after + [(len(jobs) - 1, None)]:
+                if k_ + 1 > start:
+                    copied += M.copy_ranges([j_[:5] for j_ in jobs[start:k_ + 1]], threads)
+                    start = k_ + 1
+                if s_i is not None and not (take_first and s_i == 0):
+                    shards[s_i].close()
+                    done_shards.add(s_i)
+                    remover.remove(paths[s_i])
+            for s_i in range(len(shards)):                               # shards without a row
+                if s_i not in done_shards and not (take_first and s_i == 0):
+                    shards[s_i].close()
+                    remover.remove(paths[s_i])
             # ---- reads + run-info tables, footer
             with os.fdopen(os.dup(fd), "r+b") as f:
                 f.seek(end_of_batches + len(tail))
                 f.truncate()
                 _write_tail(f, pa, meta, marker, file_identifier, sig_start, run_infos, cols, run_ids, pore_types)
-        merge_pod5.last = {"bytes_copied": int(copied) + sum(len(b_) for _, b_ in stash), "seconds": time.perf_counter() - t0,
-                           "signal_rows": int(n), "batches_in_place": int(keep)}
+        removing = remover.finish()
+        merge_pod5.last = {"bytes_copied": int(copied), "seconds": time.perf_counter() - t0, "signal_rows": int(n),
+                           "batches_in_place": int(keep), "remove_seconds": removing, "threads": threads}
         return len(cols["read_number"])
     finally:
         for s_ in shards:

@@ -422,8 +422,9 @@ def merge_shards(paths, out: str, threads: int = None, consume: bool = False) ->
     """The out.rankN files of a sharded run (parallel.rank_output_path) -> the ONE file the reference writes (inference.py:65-79):
     BLOW5 / SLOW5 shards with identical headers (header of the first, every shard's records in order, one end-of-file marker),
     POD5 shards by pod5_io.merge_pod5.  Nothing is decompressed and no record passes through the interpreter: the payload moves as
-    byte ranges on `threads` copy threads (merge.py).  consume=True: the first shard becomes the output and the others are
-    removed (what `predict --gpus N` does).  -> number of records; merge_shards.last = {"seconds", "bytes_copied", "bytes"}.
+    byte ranges with copy_file_range (merge.py: one writer per destination file, which is what the file system rewards).
+    consume=True: the first shard becomes the output and every other one is deleted as soon as its bytes are in (what
+    `predict --gpus N` does).  -> number of records; merge_shards.last = {"seconds", "bytes_copied", "bytes"}.
     Header attributes that differ between shards (only the wall-clock exp_start_time may) are taken from the first."""
     from . import merge as M
     paths = list(paths)
@@ -449,10 +450,10 @@ def merge_shards(paths, out: str, threads: int = None, consume: bool = False) ->
     try:
         if pod5:
             from .pod5_io import merge_pod5
-            n = merge_pod5(paths, tmp, threads=threads, take_first=take_first)
+            n = merge_pod5(paths, tmp, threads=threads, take_first=take_first, consume=consume)
             stats = dict(merge_pod5.last)
         elif binary[0]:
-            n, stats = M.merge_blow5(paths, tmp, threads=threads, take_first=take_first)
+            n, stats = M.merge_blow5(paths, tmp, threads=threads, take_first=take_first, consume=consume)
         else:
             n, stats = M.merge_slow5(paths, tmp, threads=threads)
         stats["bytes"] = os.path.getsize(tmp)
@@ -465,8 +466,9 @@ def merge_shards(paths, out: str, threads: int = None, consume: bool = False) ->
             os.remove(tmp)
         raise
     if consume:
-        for p_ in paths[1 if take_first else 0:]:
-            os.remove(p_)
+        for p_ in paths:                     # (SLOW5 shards; BLOW5 / POD5 shards went while the merge ran)
+            if os.path.exists(p_):
+                os.remove(p_)
     merge_shards.last = stats
     return n
 
