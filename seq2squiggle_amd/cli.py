@@ -107,7 +107,7 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
             raise FileExistsError(f"{out} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
         import time
         t0 = time.time()
-        rc, timing = _launch_ranks(gpus)
+        rc, timing, reap = _launch_ranks(gpus)
         timing["ranks_seconds"] = time.time() - t0
         if rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
             # one output file, as the reference writes (inference.py:65-79): the first rank's file becomes OUT, the payload of the
@@ -125,6 +125,8 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
             click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {launch if launch is None else round(launch, 2)} s, "
                        f"ranks {timing['ranks_seconds']:.2f} s in all, merge {timing['merge_seconds']:.2f} s for "
                        f"{timing['merge_bytes'] / 1e9:.2f} GB]")
+        late = reap()                                       # (the merge did not wait for the ranks' teardown: see _launch_ranks)
+        rc = rc or late
         timing["total_seconds"] = time.time() - t0
         if os.environ.get("S2S_TIMING_JSON") and not os.environ.get("S2S_DRY_LAUNCH"):
             import json
@@ -161,8 +163,10 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
     logger.info("Prediction finished.")
     if os.environ.get("S2S_TIMING_DIR"):       # a rank of `predict --gpus N`: when it was ready and when it was done, for the parent's summary
         import json
-        with open(os.path.join(os.environ["S2S_TIMING_DIR"], f"rank{os.environ.get('RANK', '0')}.json"), "w") as f:
+        stamp = os.path.join(os.environ["S2S_TIMING_DIR"], f"rank{os.environ.get('RANK', '0')}.json")
+        with open(stamp + ".tmp", "w") as f:
             json.dump({"ready": t_ready, "done": time.time()}, f)
+        os.replace(stamp + ".tmp", stamp)      # (appears whole: the parent starts the merge when it sees every rank's)
 
 
 def _launch_ranks(gpus: int):
@@ -171,7 +175,8 @@ def _launch_ranks(gpus: int):
     MASTER_PORT) -- started directly: the elastic agent of torch.distributed.run costs an import of torch in the parent and a
     rendezvous before the first rank starts, and there is nothing here for it to supervise.  The first rank that fails ends the
     others (by their pids).  S2S_DRY_LAUNCH=1 prints the child command and environment instead of running it.
-    -> (exit code, {"launch_seconds": spawn -> the slowest rank is ready to read its input, "predict_seconds": ... -> the slowest is done})."""
+    -> (exit code, {"launch_seconds": spawn -> the slowest rank is ready to read its input, "predict_seconds": ... -> the slowest is
+    done}, reap): returns as soon as every rank's output file is complete and closed; reap() collects the processes afterwards."""
     import json
     import os
     import shutil
@@ -198,13 +203,33 @@ def _launch_ranks(gpus: int):
                           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
     if os.environ.get("S2S_DRY_LAUNCH"):
         click.echo(json.dumps({"dry_launch": cmd, "rank_env": [rank_env(r) for r in range(gpus)]}))
-        return 0, {}
+        return 0, {}, lambda: 0
     timing_dir = tempfile.mkdtemp(prefix="s2s-ranks-")
     base = dict(os.environ, S2S_TIMING_DIR=timing_dir)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     t0 = time.time()
     procs = [subprocess.Popen(cmd, env=dict(base, **rank_env(r))) for r in range(gpus)]
     rc = 0
+
+    def stamps():
+        try:
+            names = os.listdir(timing_dir)
+            return [json.load(open(os.path.join(timing_dir, f))) for f in names if f.endswith(".json")]
+        except (OSError, ValueError):
+            return []
+
+    def reap() -> int:
+        """Waits for the ranks that are still shutting down (interpreter, torch and HIP teardown: ~0.3 s each, which the merge
+        does not have to wait for) -> the first non-zero exit code, or 0."""
+        code = 0
+        for p_ in procs:
+            try:
+                code = code or p_.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+                code = code or 1
+        shutil.rmtree(timing_dir, ignore_errors=True)
+        return code
     try:
         try:                                    # the merge's imports (numpy, pyarrow, the library) load while the ranks work
             from . import merge, pod5_io, signal_io  # noqa: F401
@@ -214,7 +239,9 @@ def _launch_ranks(gpus: int):
         except Exception:                       # (reported by the merge itself, if it comes to that)
             pass
         left = set(range(gpus))
-        while left:
+        # a rank writes its stamp when its output file is complete and closed (end of `predict`): once every rank has, the files
+        # can be joined -- the processes may still be tearing down
+        while left and sum(f.endswith(".json") for f in os.listdir(timing_dir)) < gpus:
             for r in sorted(left):
                 code = procs[r].poll()
                 if code is None:
@@ -226,21 +253,22 @@ def _launch_ranks(gpus: int):
                     for q in left:
                         procs[q].terminate()
             if left:
-                time.sleep(0.02)
-    finally:
+                time.sleep(0.01)
+    except BaseException:
         for p_ in procs:
             if p_.poll() is None:
                 p_.kill()
-        timing = {}
-        try:
-            rows = [json.load(open(os.path.join(timing_dir, f))) for f in os.listdir(timing_dir)]
-            if len(rows) == gpus:
-                timing = {"launch_seconds": max(x["ready"] for x in rows) - t0,
-                          "predict_seconds": max(x["done"] for x in rows) - max(x["ready"] for x in rows)}
-        except (OSError, ValueError):
-            pass
-        shutil.rmtree(timing_dir, ignore_errors=True)
-    return rc, timing
+        raise
+    timing = {}
+    rows = stamps() if rc == 0 else []
+    if len(rows) < gpus and rc == 0 and not left:      # every rank exited cleanly; a stamp may have been written a moment ago
+        rows = stamps()
+    if len(rows) == gpus:
+        timing = {"launch_seconds": max(x["ready"] for x in rows) - t0,
+                  "predict_seconds": max(x["done"] for x in rows) - max(x["ready"] for x in rows)}
+    elif rc == 0:
+        rc = reap() or 1                              # a rank ended without its stamp: not a complete set of files
+    return rc, timing, reap
 
 
 @main.command("merge-shards")

@@ -401,6 +401,7 @@ def test_a_run_far_above_the_redo_threshold_on_the_fast_path_says_so(tmp_path, c
 
     def run(weights, out, path):
         caplog.clear()
+        U.set_seeds(9)                     # (the CLI does this before inference_run: the read sampler draws from the global generators)
         with caplog.at_level(logging.INFO, logger="seq2squiggle"):
             m = inference_run(config=set_config(None), saved_weights=weights, fasta=lam, read_input=False, n=12, r=1500, c=-1,
                               out=str(out), profile="dna-r10-prom", dwell_mean=None, dwell_std=0.0, noise_std=2.0, noise_sampling=True,

@@ -704,14 +704,18 @@ if os.environ.get("STUB_FAIL_RANK") == str(rank):
     sys.exit(7)
 if os.environ.get("STUB_FAIL_RANK") is not None:
     time.sleep(30)                       # the parent must end this rank when its sibling fails
-with open(os.path.join(os.environ["S2S_TIMING_DIR"], "rank%d.json" % rank), "w") as f:
+stamp = os.path.join(os.environ["S2S_TIMING_DIR"], "rank%d.json" % rank)
+with open(stamp + ".tmp", "w") as f:
     json.dump({"ready": time.time(), "done": time.time() + 0.01}, f)
+os.replace(stamp + ".tmp", stamp)
+time.sleep(0.3)                          # teardown: the parent does not wait for it before it starts the merge
 """
 
 
 def test_launch_ranks_collects_timing_and_ends_siblings_on_failure(tmp_path, monkeypatch):
-    """cli._launch_ranks: N children with the rank environment; their ready / done stamps become launch_seconds / predict_seconds;
-    the first failing rank's exit code is returned and the others are ended (by pid) instead of running on."""
+    """cli._launch_ranks: N children with the rank environment; their ready / done stamps become launch_seconds / predict_seconds and
+    it returns as soon as every rank has left its stamp (output file complete), before the processes have exited; the first
+    failing rank's exit code is returned and the others are ended (by pid) instead of running on."""
     from seq2squiggle_amd import cli
     stub = tmp_path / "stub.py"
     stub.write_text(_RANK_STUB)
@@ -720,12 +724,14 @@ def test_launch_ranks_collects_timing_and_ends_siblings_on_failure(tmp_path, mon
     real_popen = subprocess.Popen
     monkeypatch.setattr(subprocess, "Popen", lambda cmd, env=None, **kw: real_popen([cmd[0], str(stub)], env=env, **kw))
     monkeypatch.delenv("S2S_DRY_LAUNCH", raising=False)
-    rc, timing = cli._launch_ranks(3)
+    rc, timing, reap = cli._launch_ranks(3)
     assert rc == 0 and 0 <= timing["launch_seconds"] < 30 and 0 <= timing["predict_seconds"] < 1
+    assert reap() == 0                                            # (the ranks' teardown is collected after the merge)
     monkeypatch.setenv("STUB_FAIL_RANK", "1")
     t0 = __import__("time").time()
-    rc, timing = cli._launch_ranks(3)
+    rc, timing, reap = cli._launch_ranks(3)
     assert rc == 7 and timing == {} and __import__("time").time() - t0 < 20
+    reap()
 
 
 _SEED_WORKER = r"""
