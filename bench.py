@@ -206,9 +206,9 @@ def parity_vs_oracle(sd, cfg, eng, n=256):
 
 
 def reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, steps):
-    """NOT the headline: the same workload in S2S_MODE_F16 (decoder operands rounded to f16 once -- the precision class of
-    the reference's fp16-autocast GPU path, inference.py:404 -- one MFMA product per product; frontend unchanged, so the
-    dwell indices stay bit-exact).  Reported with its measured error so that nobody has to guess what it costs."""
+    """NOT the headline: the same workload in S2S_MODE_F16 (decoder operands rounded to f16 once, one MFMA product per product;
+    frontend unchanged, so the dwell indices stay bit-exact).  Reported with its measured error, beside the error of the reference's
+    own GPU precision (fp16 autocast, inference.py:403-404) on the same chunks, so that nobody has to guess what it costs."""
     eng = S.Engine(sd, cfg, device=bases_d.device.index, mode="f16")
     eng.predict_chunks(bases_d, nv_d, params, out_signal=sig, out_dur=dur)
     torch.cuda.synchronize()
@@ -219,6 +219,29 @@ def reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, steps):
     el = time.perf_counter() - t0
     out = {"mode": "f16", "chunks_per_sec": bases_d.shape[0] * steps / el, "samples_per_sec": bases_d.shape[0] * steps * 250 / el,
            "parity": parity_vs_oracle(sd, cfg, eng), "tolerance_note": "outside the 1e-4 pA parity bound by design"}
+    # beside the reference's OWN GPU arithmetic (inference.py:403-404: "16-mixed" whenever a GPU is present): the imported reference's
+    # predict_step under fp16 autocast on the golden chunks, same injected variates (tests/golden/mixed16.npz, tools/make_goldens.py
+    # mixed16), against the mode on the same chunks -- both measured against the reference's fp32 result
+    try:
+        from seq2squiggle_amd import chunker
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "stages_k9.npz")))
+        m16 = dict(np.load(os.path.join(ROOT, "tests", "golden", "mixed16.npz")))
+        gb, gnv = chunker.codes_to_bases(g["codes"])
+        dev = bases_d.device
+        got = eng.predict_chunks(torch.from_numpy(gb).to(dev), torch.from_numpy(gnv).to(dev), S.PredictParams(),
+                                 inject_g=torch.from_numpy(g["g"]).to(dev), inject_z01=torch.from_numpy(np.ascontiguousarray(g["z01"])).to(dev))
+        y, t = got["signal"].cpu().numpy(), g["y_gamma_nsamp"]
+        agree = (m16["dur_gamma_16mixed_k9"] == g["dur_gamma"]).all(1)
+        ref_d = np.abs(m16["y_gamma_nsamp_16mixed_k9"] - t)
+        out["vs_reference_gpu_precision"] = {
+            "chunks": int(len(t)), "mode_mae_pa": float(np.abs(y - t).mean()), "mode_max_abs_pa": float(np.abs(y - t).max()),
+            "mode_dwell_indices_equal": bool(np.array_equal(got["dur"].cpu().numpy(), g["dur_gamma"])),
+            "reference_16mixed_mae_pa": float(ref_d[agree].mean()), "reference_16mixed_max_abs_pa": float(ref_d[agree].max()),
+            "reference_16mixed_mae_pa_all_chunks": float(ref_d.mean()), "reference_16mixed_dwell_indices_differing": int(m16["dwell_indices_differing_k9"]),
+            "note": "distance to the reference's fp32 golden on the golden chunks; reference_16mixed = the imported reference under "
+                    "torch.autocast(float16) (CPU stand-in for its GPU path), on the chunks whose dwell indices it keeps"}
+    except Exception as e:
+        out["vs_reference_gpu_precision"] = {"error": f"{type(e).__name__}: {e}"}
     eng.close()
     return out
 

@@ -288,18 +288,24 @@ int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off
                         const int64_t* len, int32_t threads);
 int64_t s2s_blow5_scan(int32_t fd, int64_t begin, int64_t end);
 
-/* Which softmax path the split-f16 decoder attention (S2S_MODE_F16X3 / S2S_MODE_F16) tries first (layers.py:20-40 is one
- * unmasked softmax over 250 keys; both paths compute it within the parity bound):
- *   0  the FAST path: shift = the row's maximum over its first 64 keys + 2 log2 units, no maximum in later passes, straight-line
- *      code; a head whose later keys beat that shift by more than the f16 range is detected by its row sum and redone by an
- *      out-of-line online softmax (maximum and rescale in every pass).  Best for diffuse attention (the synthetic checkpoints: 0.006 - 2 % of the heads are redone);
- *   1  the EXACT path at once: the online softmax (running row maximum raised and sums rescaled in every 64-key pass, no
- *      branch; the shift in the score MFMA's k-slots, a pass's scores issued again with the raised shift) as the only path of
- *      its own kernel instance: 9.5 % more shader cycles than the fast path on diffuse attention, the same time for ANY
- *      weights -- "fast, then redo" costs 1.5 - 1.7 x once most heads overflow (sharply peaked attention).
- * s2s_create chooses by a calibration launch on a fixed pseudo-random batch (exact when more than 8 % of its heads had to
- * be redone; the environment variable S2S_ATTENTION_PATH=fast|exact skips the launch); `calibration_redo_rate` returns that
- * share (-1 when no calibration ran).  Results are deterministic per chunk for a given path. */
+/* Which softmax path the split-f16 decoder attention (S2S_MODE_F16X3 / S2S_MODE_F16) runs (layers.py:20-40 is one unmasked
+ * softmax over 250 keys; both paths compute it within the parity bound, with the same error against an fp64 evaluation):
+ *   0  the FAST path: shift = the row's maximum over the keys of PASS 0 + 2 log2 units, no maximum in later passes, straight-line
+ *      code.  Pass 0 is a SAMPLE of the whole row -- the fast instance stores the K / V^T images with the blocks of four consecutive
+ *      keys dealt out over the four 64-key passes, so pass 0 holds the key blocks b = 0 (mod 4).  A head whose later keys beat that
+ *      shift by more than the f16 range shows in its row sum and is redone by an out-of-line online softmax.  Best for diffuse
+ *      attention (the committed synthetic checkpoints redo nothing; their decoder w_qs / w_ks x 2: 6.4 % of the heads);
+ *   1  the EXACT path at once: the online softmax (running row maximum raised and sums rescaled in every 64-key pass, no branch;
+ *      the shift rides in the score MFMA's k-slots, a pass's row maxima come from its first score MFMA alone, natural key
+ *      order) as the only path of its own kernel instance: 203.8 k shader cycles per chunk and CU against the fast path's 191.0 k
+ *      on diffuse attention (6.7 % more), the same for ANY weights -- "fast, then redo" costs 310-328 k once most heads overflow
+ *      (sharply peaked attention).
+ * s2s_create chooses by a calibration launch on a fixed pseudo-random batch: exact when more than S2S_ATTENTION_REDO_THRESHOLD of
+ * its heads had to be redone (where the two cost the same).  The environment variable S2S_ATTENTION_PATH = fast | exact (any
+ * case) skips the launch, auto or empty means calibrate, anything else makes s2s_create fail.  `calibration_redo_rate` returns
+ * the launch's share (-1 when no calibration ran).  Results are deterministic per chunk for a given path. */
+#define S2S_ATTENTION_REDO_THRESHOLD 0.055
+double s2s_attention_redo_threshold(void);
 int s2s_set_attention_path(s2s_handle* h, int32_t path);
 int s2s_get_attention_path(const s2s_handle* h, int32_t* path, double* calibration_redo_rate);
 

@@ -62,6 +62,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ONLINE2
 #define S2S_ONLINE2 1           // the exact instance runs softmax_pv32_online (0: the fast instance's out-of-line fallback, A/B)
 #endif
+#ifndef S2S_ONLINE_HI_MAX
+#define S2S_ONLINE_HI_MAX 1     // softmax_pv32_online takes a pass's row maxima from the FIRST score MFMA alone (0: from the full score, A/B)
+#endif
 #ifndef S2S_ONE_ZEROS_ROW
 #define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
 #endif
@@ -562,14 +565,29 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
             att32_mask_tile<TV, NATURAL>(sc[0], 2 * h2, h);               // phantom keys -> -inf (natural key order: tile 7 only)
             att32_mask_tile<TV, NATURAL>(sc[1], 2 * h2 + 1, h);
         };
+#if S2S_ONLINE_HI_MAX
+        // The shift only has to keep P inside the f16 range and be the SAME in the numerator and the row sum -- it need not be the
+        // exact maximum.  The first score MFMA alone ([K_hi | K_lo] . [Q_hi | Q_hi]: everything but K_hi . Q_lo, i.e. the score to
+        // 2^-11 of its size, a fraction of a log2 unit) gives the pass's row maxima for half the MFMAs of a full score pass, and
+        // unshifted: the new shift is max(old shift, this pass's maximum).
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sc[i] = MFMAW(ka[i], qb1, zero16);
+        att32_mask_tile<TV, NATURAL>(sc[0], 2 * h2, h);
+        att32_mask_tile<TV, NATURAL>(sc[1], 2 * h2 + 1, h);
+#else
         score_pass();
+#endif
         float mh = sc[0][0];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mh = fmaxf(mh, sc[i][r]);
-        mh = max_h(mh);                                                   // the row's maximum over this pass, relative to the shift
+        mh = max_h(mh);                                                   // the row's maximum over this pass (HI_MAX: absolute; else relative to the shift)
+#if S2S_ONLINE_HI_MAX
+        const float nm = -(h2 == 0 ? mh : fmaxf(m, mh));
+#else
         const float nm = -(h2 == 0 ? mh : m + fmaxf(mh, 0.0f));
+#endif
         const _Float16 nh = (_Float16)nm;
         const _Float16 nl = (_Float16)(nm - (float)nh);
         const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, nl}));

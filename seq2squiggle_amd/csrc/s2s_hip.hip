@@ -1122,7 +1122,7 @@ static int predict_impl(s2s_handle* h, void* stream_, const uint8_t* bases, cons
                         const float* inject_z01, float* out_signal, int32_t* out_dur, const s2s_debug* dbg);
 
 // Which softmax path the split-f16 decoder tries first is a property of the WEIGHTS: one launch of 512 pseudo-random chunks with the
-// default samplers on the fast path counts the heads it had to redo (the production counters); above 8 % the handle starts
+// default samplers on the fast path counts the heads it had to redo (the production counters); above S2S_ATTENTION_REDO_THRESHOLD the handle starts
 // every head on the exact path (s2s_device_h.h: the online softmax as its own kernel instance).  A fixed input, so the same weights always get the same
 // answer, on any device.  The export scratch inside the slab holds the launch's buffers.
 static int calibrate_attention(s2s_handle* h) {
@@ -1150,11 +1150,14 @@ static int calibrate_attention(s2s_handle* h) {
     const int rs = s2s_stats_read(h, st);
     if (rs != S2S_OK) return rs;
     h->calib_redo_rate = st[1] ? (double)st[2] / (double)st[1] : 0.0;
-    // (measured: a redone head also holds its seven partner waves at the next barrier, so a redo share r costs ~ 200 k x r cycles per
-    //  chunk while r is small -- 1.7 %: + 3.2 k, 10.4 %: + 22.8 k -- and 153 k x r once most heads redo; the exact instance costs + 19.8 k)
-    h->attn_exact = h->calib_redo_rate > 0.08 ? 1 : 0;
+    // (measured: a redone head also holds its seven partner waves at the next barrier, so a redo share r costs ~ 235 k x r cycles per
+    //  chunk while r is small -- 6.4 %: + 15.0 k -- and 153 k x r once most heads redo; the exact instance costs + 12.8 k whatever the
+    //  weights (203.8 k against 191.0 k, profiles/r05/attention_paths.txt): they break even at r = 5.5 %)
+    h->attn_exact = h->calib_redo_rate > S2S_ATTENTION_REDO_THRESHOLD ? 1 : 0;
     return S2S_OK;
 }
+
+double s2s_attention_redo_threshold(void) { return S2S_ATTENTION_REDO_THRESHOLD; }
 
 int s2s_create(const s2s_config* cfg, const void* blob, size_t blob_bytes, int device, s2s_handle** out) {
     if (!out) return fail(nullptr, S2S_ERR_ARG, "out is NULL");

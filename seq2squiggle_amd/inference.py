@@ -17,7 +17,12 @@ from .utils import get_profile, get_reads, update_config, update_profile
 logger = logging.getLogger("seq2squiggle")
 
 
-REDO_WARN_RATE = 0.08        # the threshold of s2s_create's calibration (csrc/s2s_hip.hip: calibrate_attention)
+def redo_threshold() -> float:
+    """The redo share above which the exact attention instance is the faster one: the threshold of s2s_create's calibration
+    (include/s2s_hip.h: S2S_ATTENTION_REDO_THRESHOLD)."""
+    from ._lib import lib
+    fn = getattr(lib(), "s2s_attention_redo_threshold", None)
+    return float(fn()) if fn is not None else 0.055
 
 
 def get_writer(out: str, profile: object, ideal_mode: bool, export_every_n_samples: int, profile_name: str,
@@ -454,10 +459,10 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
     logger.debug(f"attention path {eng.attention_path} (calibration launch: {100 * eng.calibration_redo_rate:.2f} % of the heads redone); "
                  f"this run: {100 * st['redo_rate']:.3f} % redone, {st['in_kernel_clock_ghz'] or 0:.2f} GHz in the kernel, "
                  f"{st['cycles_per_chunk_and_cu'] or 0:.0f} cycles per chunk and CU")
-    if eng.attention_path == "fast" and st["redo_rate"] > REDO_WARN_RATE:
+    if eng.attention_path == "fast" and st["redo_rate"] > redo_threshold():
         logger.warning(f"{100 * st['redo_rate']:.1f} % of the attention heads of this run overflowed the fast softmax path and were redone "
                        f"(the checkpoint's calibration launch saw {100 * max(eng.calibration_redo_rate, 0):.1f} %; above "
-                       f"{100 * REDO_WARN_RATE:.0f} % the exact path is faster). The output is the same either way; "
+                       f"{100 * redo_threshold():.1f} % the exact path is faster). The output is the same either way; "
                        f"for this kind of input run with --attention-path exact.")
     shard = rank_output_path(str(out), rank, world)
     if world > 1 and not os.path.exists(shard) and hasattr(writer, "write_records"):

@@ -386,7 +386,7 @@ def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
 
 def test_a_run_far_above_the_redo_threshold_on_the_fast_path_says_so(tmp_path, caplog):
     """the calibration launch decides the attention path on 512 pseudo-random chunks; a RUN that ends on the
-    fast path with more than 8 % of its heads redone (here: the decoder's w_qs / w_ks x 4 forced onto the fast path, 79 %) logs a
+    fast path with more than the calibration's threshold (5.5 %) of its heads redone (here: the decoder's w_qs / w_ks x 4 forced onto the fast path, 79 %) logs a
     WARNING that names `--attention-path exact` -- at the default verbosity, not at debug -- and the output is the file the exact
     path writes (no run-time switching: a chunk's result never depends on its batch).  The committed checkpoint says nothing."""
     import logging

@@ -14,8 +14,9 @@ for m in f16x3 f32; do
 done
 # the exact attention instance (s2s_fused_kernel<1, false, true>) forced on the same workload: kernel stats only
 S2S_ATTENTION_PATH=exact rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats_f16x3_exact -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode f16x3 > $R/gpurun_out/$T/bench_f16x3_exact_under_rocprof.json 2> $R/gpurun_out/$T/stats_f16x3_exact.err
+S2S_ATTENTION_PATH=exact bash $R/tools/pmc_run.sh $T/pmc_f16x3_exact --mode f16x3
 cd $R && python3 bench.py > gpurun_out/$T/bench_f16x3.json 2> gpurun_out/$T/bench_f16x3.err
-python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32:65520 f16x3=gpurun_out/$T/pmc_f16x3:65520 > gpurun_out/$T/pmc_summary.json
+python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32:65520 f16x3=gpurun_out/$T/pmc_f16x3:65520 f16x3_exact=gpurun_out/$T/pmc_f16x3_exact:65520 > gpurun_out/$T/pmc_summary.json
 # the un-profiled diagnostic build: per-wave phase stamps + the clock the SIMDs held (s_memtime / s_memrealtime)
 S2S_DIAG_HEAT=3 python3 tools/diag_phases.py f16x3 > gpurun_out/$T/diag_phases.txt 2>&1
 S2S_DIAG_HEAT=2 python3 tools/diag_phases.py f32 > gpurun_out/$T/diag_phases_f32.txt 2>&1
