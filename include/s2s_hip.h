@@ -310,8 +310,9 @@ int s2s_set_attention_path(s2s_handle* h, int32_t path);
 int s2s_get_attention_path(const s2s_handle* h, int32_t* path, double* calibration_redo_rate);
 
 /* Counters of the predict kernel since the last call (every build; synchronises the device, then resets them).  The fast
- * softmax of the split-f16 decoder is data dependent -- a head whose later keys beat the first 64 keys' maximum by more than
- * the f16 range is redone on a safe path -- and the chip's clock under this kernel depends on the operands, so a throughput
+ * softmax of the split-f16 decoder is data dependent -- a head whose later keys beat the maximum over its pass-0 key sample (the
+ * key blocks b = 0 mod 4, see s2s_set_attention_path) by more than the f16 range is redone on a safe path -- and the chip's clock
+ * under this kernel depends on the operands, so a throughput
  * figure is a statement about one set of weights: these counters say how a run behaved.  out10 =
  *   [0] chunks launched, [1] (wave, head, layer) softmax runs (chunks x 8 waves x 8 heads x decoder layers),
  *   [2] ... of them redone on the safe path (0 in S2S_MODE_F32, which has no fast path),

@@ -522,11 +522,15 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     }
 }
 // The EXACT attention path (s2s_fused_kernel<.., EXACT = true>, s2s_set_attention_path; s2s_create picks it for weights whose
-// calibration launch redoes more than 8 % of its heads) is the online softmax -- running maximum raised and sums rescaled in
-// every 64-key pass, branch-free -- as the ONLY path of its kernel instance: the same shader cycles per chunk on every
-// checkpoint, whatever the weights, where "fast path, then redo" costs 188.6 k on diffuse attention and 279-325 k once most
+// calibration launch redoes more than S2S_ATTENTION_REDO_THRESHOLD of its heads) is the online softmax -- running maximum raised
+// and sums rescaled in every 64-key pass, branch-free -- as the ONLY path of its kernel instance: the same shader cycles per chunk
+// on every checkpoint, whatever the weights (203.8 k, profiles/r05/attention_paths.txt), where "fast path, then redo" costs 191.0 k on
+// diffuse attention and 310-328 k once most
 // heads overflow.  As softmax_pv32<TV, SAFE = true> (the fast instance's out-of-line fallback) it measured 221.7 k; as
-// softmax_pv32_online below 206.5 k.  Three cleverer exact paths were built in round 4 and lost to it (LABNOTES.md,
+// softmax_pv32_online below 209.0 k with every pass's maxima taken from the full score (206.5 k on round 4's device, 211.8 k while
+// the exact instance still shared the fast one's dealt-out key order: the phantom-key masks sat in two passes and the kernel
+// spilled 7 registers), 203.8 k with the maxima from the first score MFMA alone (S2S_ONLINE_HI_MAX, round 5).
+// Three cleverer exact paths were built in round 4 and lost to it (LABNOTES.md,
 // profiles/r04/attention_paths_*.txt; their code is in commits 3a2cca9 and the two after b739589):
 //  * exact running maximum with lazy re-centring and every 16-key step CLASSIFIED by its largest shifted score (skipped below
 //    -32, P_lo dropped below -16): 229-251 k, 224 k with 51 % of the steps skipped.  The verdict has to be wave-uniform, i.e. a

@@ -6,6 +6,14 @@ For every kernel the counters of its FIRST dispatch in each pass (tools/pmc_run.
 Scratch_Size / VGPR_Count are kept so the launch can be identified."""
 import csv, glob, json, os, sys
 
+def _is_test_instance(name):
+    """s2s_fused_kernel<MODE, TEST, EXACT>: TEST = true is s2s_create's 512-chunk calibration launch (and the parity tests' instance)."""
+    if "s2s_fused_kernel<" not in name:
+        return False
+    args = [a.strip() for a in name.split("s2s_fused_kernel<", 1)[1].split(">")[0].split(",")]
+    return len(args) > 1 and args[1] == "true"
+
+
 out = {}
 for arg in sys.argv[1:]:
     mode, d = arg.split("=", 1)
@@ -24,7 +32,7 @@ for arg in sys.argv[1:]:
                                      "scratch_bytes_per_lane": int(row["Scratch_Size"]), "vgprs": int(row["VGPR_Count"]),
                                      "lds_bytes": int(row["LDS_Block_Size"]),
                                      # (the TEST instance of the fused kernel is s2s_create's calibration launch: 512 chunks)
-                                     **({"chunks": 512 if "s2s_fused_kernel<" in name and ", true" in name.split(">")[0] else int(chunks)} if chunks else {})})
+                                     **({"chunks": 512 if _is_test_instance(name) else int(chunks)} if chunks else {})})
     # wall time of that first dispatch in every pass (pmcN_kernel_trace.csv), so that a counter can be turned into a rate: the
     # clock the chip held in the pass that counted GRBM_GUI_ACTIVE is GRBM_GUI_ACTIVE / 8 XCDs / that pass's duration
     for path in sorted(glob.glob(os.path.join(d, "pmc*_kernel_trace.csv"))):
