@@ -62,9 +62,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ONLINE2
 #define S2S_ONLINE2 1           // the exact instance runs softmax_pv32_online (0: the fast instance's out-of-line fallback, A/B)
 #endif
-#ifndef S2S_EXACT_TWO_PHASE
-#define S2S_EXACT_TWO_PHASE 0   // the exact instance as row maxima first, then the fast path's body (softmax_pv32_exact2; A/B)
-#endif
 #ifndef S2S_ONLINE_HI_MAX
 #define S2S_ONLINE_HI_MAX 1     // softmax_pv32_online takes a pass's row maxima from the FIRST score MFMA alone (0: from the full score, A/B)
 #endif
@@ -533,6 +530,9 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 // softmax_pv32_online below 209.0 k with every pass's maxima taken from the full score (206.5 k on round 4's device, 211.8 k while
 // the exact instance still shared the fast one's dealt-out key order: the phantom-key masks sat in two passes and the kernel
 // spilled 7 registers), 203.8 k with the maxima from the first score MFMA alone (S2S_ONLINE_HI_MAX, round 5).
+// (Round 5 also tried it in two phases -- the row maxima of all eight tiles from that first MFMA, then the fast path's body with the
+// exact shift, no update or rescale in the loop, commit 7131d25: unrolled, hipcc hoists phase 1 to the front and spills 52 registers; as
+// a real loop it runs 218.8 k: the separate phase exposes the K reads and the MFMA chain that the online loop hides.)
 // Three cleverer exact paths were built in round 4 and lost to it (LABNOTES.md,
 // profiles/r04/attention_paths_*.txt; their code is in commits 3a2cca9 and the two after b739589):
 //  * exact running maximum with lazy re-centring and every 16-key step CLASSIFIED by its largest shifted score (skipped below
@@ -609,68 +609,6 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
         }
         m = m_enc;
         score_pass();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
-                exp_split4<LO>(f32x4{sc[i][8 * st], sc[i][8 * st + 1], sc[i][8 * st + 2], sc[i][8 * st + 3]}, one, h0, h1, l0, l1);
-                exp_split4<LO>(f32x4{sc[i][8 * st + 4], sc[i][8 * st + 5], sc[i][8 * st + 6], sc[i][8 * st + 7]}, one, h2_, h3, l2, l3);
-                O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
-                if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
-            }
-    }
-}
-// The exact path in TWO PHASES (S2S_EXACT_TWO_PHASE, A/B): phase 1 takes the row maxima over ALL keys from the first score MFMA
-// of every tile (as S2S_ONLINE_HI_MAX does per pass) -- K is read from LDS a second time, nothing else is kept -- phase 2 is the
-// fast path's body with that shift: no maximum, no shift update and no rescale of O inside the loop.  (Round 4's two-pass variant
-// ran the FULL score in its first pass and kept it alive: 280 k cycles, 93 spilled registers.)
-template <int TV, bool LO, bool NATURAL>
-__device__ __forceinline__ void softmax_pv32_exact2(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
-                                                    const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O) {
-    constexpr int NT = 8;
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto k_of = [&](const int t) { return *reinterpret_cast<const h8*>(kp + 32 * t * 8); };
-    auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
-    static_assert(NATURAL && TV > 32 * (NT - 1), "natural key order: the phantom keys sit in the last tile only");
-    float mh = -__builtin_inff();
-    // two tiles per step, as a REAL loop: unrolled, hipcc hoists the K reads and MFMAs of all eight tiles to the front and spills 52
-    // registers; the last pair (the one with the phantom-key mask, a compile-time pattern) stands outside
-#pragma unroll 1
-    for (int t = 0; t < NT - 2; t += 2) {
-        const f32x16 a = MFMAW(k_of(t), qb1, zero16), b = MFMAW(k_of(t + 1), qb1, zero16);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mh = fmaxf(mh, fmaxf(a[r], b[r]));
-    }
-    {
-        f32x16 a = MFMAW(k_of(NT - 2), qb1, zero16), b = MFMAW(k_of(NT - 1), qb1, zero16);
-        att32_mask_tile<TV, NATURAL>(b, NT - 1, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mh = fmaxf(mh, fmaxf(a[r], b[r]));
-    }
-    const float nm = -max_h(mh);
-    const _Float16 nh = (_Float16)nm;
-    const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, (_Float16)(nm - (float)nh)}));
-    uv4 q2 = __builtin_bit_cast(uv4, qb2);
-    q2[0] = h ? pk : q2[0];
-    const h8 qb2m = __builtin_bit_cast(h8, q2);
-    __builtin_amdgcn_sched_barrier(0);
-    O = zero16;
-#pragma unroll
-    for (int h2 = 0; h2 < NT / 2; ++h2) {
-        h8 ka[2], kb[2], va[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ka[i] = k_of(2 * h2 + i);
-            kb[i] = *reinterpret_cast<const h8*>(kp2 + (2 * h2 + i) * (h ? 0 : 32 * 8));
-            va[i][0] = v_of(2 * h2 + i, 0); va[i][1] = v_of(2 * h2 + i, 1);
-        }
-        SB_ATT();
-        f32x16 sc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
-        att32_mask_tile<TV, NATURAL>(sc[0], 2 * h2, h);
-        att32_mask_tile<TV, NATURAL>(sc[1], 2 * h2 + 1, h);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -874,9 +812,7 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
                     f32x16 O;
                     float lsum;
                     if constexpr (EXACT) {                                 // the handle's attention path is "exact" (its own kernel instance)
-#if S2S_EXACT_TWO_PHASE && S2S_ATT32_MSLOT
-                        softmax_pv32_exact2<TV, LO, true>(kp, kp2, vp, qb1, qb2, one, hl, O);
-#elif S2S_ONLINE2 && S2S_ATT32_MSLOT
+#if S2S_ONLINE2 && S2S_ATT32_MSLOT
                         softmax_pv32_online<TV, LO, true>(kp, kp2, vp, qb1, qb2, one, hl, O);
 #else
                         softmax_pv32<TV, true, LO, true>(kp, kp2, vp, qb1, qb2, one, hl, O);
