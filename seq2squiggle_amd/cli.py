@@ -128,6 +128,11 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
         late = reap()                                       # (the merge did not wait for the ranks' teardown: see _launch_ranks)
         rc = rc or late
         timing["total_seconds"] = time.time() - t0
+        try:
+            import resource
+            timing["parent_peak_rss_mb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0      # the join keeps no payload in memory
+        except (ImportError, OSError):
+            pass
         if os.environ.get("S2S_TIMING_JSON") and not os.environ.get("S2S_DRY_LAUNCH"):
             import json
             with open(os.environ["S2S_TIMING_JSON"], "w") as f:
