@@ -276,16 +276,18 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
 
 /* ---- host-side helpers of the rank-shard merge (no GPU work, no handle; `predict --gpus N` / `merge-shards`): the reference
  * leaves ONE output file (inference.py:65-79, signal_io.py:167-171, 268-282), a sharded run one per rank.
- * s2s_copy_ranges copies n byte ranges (src_fd[i], src_off[i], len[i]) -> (dst_fd[i], dst_off[i]) on `threads` threads with
- * copy_file_range (in the kernel, no user-space buffer; pread / pwrite through a bounce buffer where the file system refuses it);
- * ranges must not overlap inside one file.  One destination file has one fast writer (the inode lock; measured in
- * profiles/r05/fs_write_probe_shm.txt: 6.5 GB/s with one writer, 3.2-4.1 GB/s with 2-8), so pass threads = 1 per destination.
- * Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the failing call).
+ * s2s_copy_ranges copies n byte ranges (src_fd[i], src_off[i], len[i]) -> (dst_fd[i], dst_off[i]); ranges must not overlap inside
+ * one file.  engine 0: copy_file_range on the descriptors (in the kernel, no user-space buffer; pread / pwrite through a bounce
+ * buffer where the file system refuses it), ONE writer whatever `threads` says -- buffered writes of one file take its inode lock and
+ * more writers are slower (profiles/r05/fs_write_probe_shm.txt: 6.5 GB/s with one, 3.2-4.1 GB/s with 2-8).  engine 1: the
+ * destination ranges are allocated first (posix_fallocate: 18.6 GB/s on that box) and then filled by memcpy between shared
+ * mappings on `threads` threads (stores into existing pages take no lock: 20 GB/s with 8); when the file system refuses the
+ * allocation or a mapping, engine 0 runs instead.  Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the failing call).
  * s2s_blow5_scan walks the [u64 size][body] records of a BLOW5 file between byte offsets begin and end (the end of the
  * header and the start of the end-of-file marker) reading the size prefixes only: the record count, or -2 when the chain of
  * sizes does not end exactly at `end` (a truncated shard). */
 int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd, const int64_t* dst_off,
-                        const int64_t* len, int32_t threads);
+                        const int64_t* len, int32_t threads, int32_t engine);
 int64_t s2s_blow5_scan(int32_t fd, int64_t begin, int64_t end);
 
 /* Which softmax path the split-f16 decoder attention (S2S_MODE_F16X3 / S2S_MODE_F16) runs (layers.py:20-40 is one unmasked

@@ -76,7 +76,7 @@ def lib():
     bind("s2s_fastq_clean", i64, [vp, i64, i32, vp, vp, vp, i64])
     bind("s2s_fasta_count", i64, [vp, i64])
     bind("s2s_fasta_clean", i64, [vp, i64, i32, vp, vp, vp, i64])
-    bind("s2s_copy_ranges", i64, [i32, vp, vp, vp, vp, vp, i32])
+    bind("s2s_copy_ranges", i64, [i32, vp, vp, vp, vp, vp, i32, i32])
     bind("s2s_blow5_scan", i64, [i32, i64, i64])
     bind("s2s_attention_redo_threshold", C.c_double, [])
     _lib = L

@@ -906,7 +906,11 @@ extern "C" int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_a
 // writes one per rank, and joining them must not cost more than the ranks' parallel phase did.  Both helpers work on file
 // descriptors; nothing passes through the interpreter or (copy_file_range) through user space.
 #include <cerrno>
+#include <climits>
 #include <fcntl.h>
+#include <map>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace {
@@ -938,25 +942,72 @@ int64_t copy_one(int src, int64_t src_off, int dst, int64_t dst_off, int64_t len
 
 }  // namespace
 
-// One destination file has ONE fast writer: buffered writes (pwrite, copy_file_range) take its inode lock, and stores through a
-// shared mapping -- which take no such lock -- fill the page cache no faster (the page allocation is the bound).  Measured on the
-// MI355X box's host (profiles/r05/fs_write_probe_*.txt, merge_bench_*_mapped_vs_fd.txt): one writer fills a tmpfs file at 6.5 GB/s,
-// 2-8 concurrent writers of the SAME file at 3.2-4.1 GB/s, a mapped copy at 3.0-4.5 GB/s with 1-16 threads; separate files scale
-// (42 GB/s with 8 writers).  So `threads` is the caller's knob (seq2squiggle_amd/merge.py passes 1 per destination), not a default
-// to raise; the mapped engine of commit 1b15c95 was dropped.
+// Two engines.
+//  * descriptors (engine 0): copy_file_range, in the kernel.  One destination file has ONE fast writer this way: buffered writes
+//    take its inode lock, so 2-8 threads into the SAME file are slower than one (3.2-4.1 against 6.5 GB/s on the MI355X box's tmpfs,
+//    profiles/r05/fs_write_probe_shm.txt), and what a lone writer spends its time on is allocating the destination's pages.
+//  * preallocate + mapped copy (engine 1): posix_fallocate() the destination ranges first -- allocation WITHOUT data runs at 18.6 GB/s
+//    there -- then memcpy between shared mappings of the files on `threads` threads: stores into pages that already exist take
+//    no lock and no allocation and scale with the memory system (20 GB/s with 8 writers against 10 GB/s for a lone pwrite into the
+//    same preallocated file).  The space is reserved before the first store, so a full file system is an error code (the fallocate
+//    fails, engine 0 takes over and reports ENOSPC), never a SIGBUS.  Round 5's first mapped engine (commit 1b15c95) stored into
+//    pages that did NOT exist yet and lost to copy_file_range everywhere: the page allocation under the faults was the bound.
+namespace {
+struct Span { int64_t lo = INT64_MAX, hi = 0; uint8_t* base = nullptr; size_t bytes = 0; };      // the hull of a file's ranges, and its mapping
+
+bool map_spans(std::map<int, Span>& spans, bool writable) {
+    for (auto& kv : spans) {
+        Span& sp = kv.second;
+        sp.lo &= ~(int64_t)4095;                                     // (mmap wants a page-aligned file offset)
+        sp.bytes = (size_t)(sp.hi - sp.lo);
+        void* m = mmap(nullptr, sp.bytes, writable ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, kv.first, (off_t)sp.lo);
+        if (m == MAP_FAILED) { sp.base = nullptr; return false; }
+        sp.base = static_cast<uint8_t*>(m);
+    }
+    return true;
+}
+void unmap_spans(std::map<int, Span>& spans) {
+    for (auto& kv : spans)
+        if (kv.second.base) munmap(kv.second.base, kv.second.bytes);
+}
+}  // namespace
+
 extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd,
-                                   const int64_t* dst_off, const int64_t* len, int32_t threads) {
-    if (n < 0 || threads < 1 || (n > 0 && (!src_fd || !src_off || !dst_fd || !dst_off || !len))) return S2S_ERR_ARG;
-    // pieces of <= 64 MiB, so that one long range does not leave the other threads (when asked for) idle
+                                   const int64_t* dst_off, const int64_t* len, int32_t threads, int32_t engine) {
+    if (n < 0 || threads < 1 || engine < 0 || engine > 1 || (n > 0 && (!src_fd || !src_off || !dst_fd || !dst_off || !len))) return S2S_ERR_ARG;
+    // pieces of <= 16 MiB, so that one long range does not leave the other threads idle
     struct Piece { int src, dst; int64_t so, d_o, len; };
     std::vector<Piece> pieces;
-    const int64_t cut = 64ll << 20;
+    const int64_t cut = 16ll << 20;
     int64_t total = 0;
+    std::map<int, Span> srcs, dsts;
     for (int i = 0; i < n; ++i) {
         if (len[i] < 0 || src_off[i] < 0 || dst_off[i] < 0) return S2S_ERR_ARG;
+        if (len[i] == 0) continue;
         for (int64_t o = 0; o < len[i]; o += cut)
             pieces.push_back({src_fd[i], dst_fd[i], src_off[i] + o, dst_off[i] + o, std::min(cut, len[i] - o)});
         total += len[i];
+        Span& a = srcs[src_fd[i]];
+        a.lo = std::min(a.lo, src_off[i]); a.hi = std::max(a.hi, src_off[i] + len[i]);
+        Span& b = dsts[dst_fd[i]];
+        b.lo = std::min(b.lo, dst_off[i]); b.hi = std::max(b.hi, dst_off[i] + len[i]);
+    }
+    if (pieces.empty()) return 0;
+    bool mapped = engine == 1;
+    if (mapped)
+        for (auto& kv : dsts) {
+            if (srcs.count(kv.first)) { mapped = false; break; }             // a file copied onto itself: descriptors
+            struct stat st;
+            if (fstat(kv.first, &st) != 0 || !S_ISREG(st.st_mode)) { mapped = false; break; }
+            if (posix_fallocate(kv.first, (off_t)kv.second.lo, (off_t)(kv.second.hi - kv.second.lo)) != 0) { mapped = false; break; }
+        }
+    if (mapped) {
+        for (auto& kv : srcs) {                                              // (a source shorter than its ranges would fault: checked here)
+            struct stat st;
+            if (fstat(kv.first, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < kv.second.hi) { mapped = false; break; }
+        }
+        mapped = mapped && map_spans(srcs, false) && map_spans(dsts, true);
+        if (!mapped) { unmap_spans(srcs); unmap_spans(dsts); }
     }
     std::atomic<size_t> next{0};
     std::atomic<int64_t> err{0};
@@ -967,15 +1018,22 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
             const size_t i = next.fetch_add(1);
             if (i >= pieces.size() || err.load()) return;
             const Piece& p = pieces[i];
+            if (mapped) {
+                const Span& a = srcs[p.src];
+                const Span& b = dsts[p.dst];
+                std::memcpy(b.base + (p.d_o - b.lo), a.base + (p.so - a.lo), (size_t)p.len);
+                continue;
+            }
             const int64_t r = copy_one(p.src, p.so, p.dst, p.d_o, p.len, bounce, in_kernel);
             if (r < 0) err = r;
         }
     };
-    const int workers = (int)std::min<size_t>((size_t)threads, std::max<size_t>(pieces.size(), 1));
+    const int workers = (int)std::min<size_t>((size_t)(mapped ? threads : 1), std::max<size_t>(pieces.size(), 1));   // (descriptors: one writer)
     std::vector<std::thread> pool;
     for (int w = 1; w < workers; ++w) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
+    if (mapped) { unmap_spans(srcs); unmap_spans(dsts); }
     return err.load() < 0 ? err.load() : total;
 }
 

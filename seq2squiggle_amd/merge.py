@@ -2,14 +2,17 @@
 leaves (inference.py:65-79; signal_io.py:167-171, 268-282) without re-reading a record in the interpreter.
 
 A shard's payload -- the BLOW5 record section, the lines of a SLOW5 file, the buffers of a POD5 signal table -- is a handful of
-byte ranges whose place in the merged file follows from prefix sums, so the merge is: lay out, copy every range with
-copy_file_range (s2s_copy_ranges in libs2s_hip.so: in the kernel, no user-space buffer), then write the few KB that are new
-(BLOW5: the end marker; POD5: batch metadata, the reads table, the footers -- pod5_io.merge_pod5).
+byte ranges whose place in the merged file follows from prefix sums, so the merge is: lay out, copy every range
+(s2s_copy_ranges in libs2s_hip.so), then write the few KB that are new (BLOW5: the end marker; POD5: batch metadata, the reads
+table, the footers -- pod5_io.merge_pod5).
 
-What bounds it is the file system, not this code: ONE destination file is filled by ONE writer at a time (the inode lock), at
-4.7-6.6 GB/s on the MI355X box's tmpfs and 6.5-11 GB/s into its page cache; more writers of the same file are SLOWER there
-(3.2-4.1 GB/s), while separate files scale to 42 GB/s (profiles/r05/fs_write_probe_*.txt) -- which is why the ranks write
-their own files and the join is one sequential pass.  Hence one copy thread by default.
+What bounds it is how the file system lets ONE file be filled (profiles/r05/fs_write_probe_shm.txt, the MI355X box's tmpfs): a
+buffered writer (pwrite, copy_file_range) holds the inode lock and allocates the pages as it goes -- 6.5 GB/s, and 2-8 such
+writers of the same file are SLOWER (3.2-4.1 GB/s), while separate files scale to 42 GB/s, which is why the ranks write their own
+files.  But allocating the pages WITHOUT data (posix_fallocate) runs at 18.6 GB/s, and stores through a shared mapping into pages
+that already exist take no lock and scale with the memory system (20 GB/s with 8 writers).  Hence the default engine: reserve a
+shard's destination range, then memcpy it between mappings on several threads (engine "map"); `S2S_MERGE_ENGINE=fd` selects
+copy_file_range with one writer (what every file system supports; also the automatic fallback).
 `take_first=True` turns the first shard INTO the output file (its payload is already where it belongs: 1/N fewer bytes move);
 `consume=True` deletes every other shard as soon as its bytes are in the output, on a helper thread beside the copy of the
 next one (freeing 6 GB of tmpfs pages takes 0.5 s, and the pages go straight back to the copy: the peak is the output + one shard,
@@ -25,9 +28,16 @@ import numpy as np
 BLOW5_EOF = b"5WOLB"
 
 
+def merge_engine() -> int:
+    """0: copy_file_range on descriptors, one writer; 1 (default): preallocate the destination range, then memcpy between shared
+    mappings on merge_threads() threads (falls back to 0 where the file system refuses).  S2S_MERGE_ENGINE = fd | map."""
+    return 0 if os.environ.get("S2S_MERGE_ENGINE", "map").lower().startswith("f") else 1
+
+
 def merge_threads() -> int:
-    """Copy threads per destination file: 1 (see the module text); S2S_MERGE_THREADS overrides."""
-    return max(1, int(os.environ.get("S2S_MERGE_THREADS", "0") or 0) or 1)
+    """Copy threads of the mapped engine: up to 8 of this process's CPU share (the measured knee); S2S_MERGE_THREADS overrides."""
+    from .signal_io import cpu_share
+    return max(1, int(os.environ.get("S2S_MERGE_THREADS", "0") or 0) or min(8, cpu_share()))
 
 
 class _Remover:
@@ -55,39 +65,35 @@ class _Remover:
         return self.seconds
 
 
-def copy_ranges(jobs: Sequence[Tuple[int, int, int, int, int]], threads: int = None) -> int:
+def copy_ranges(jobs: Sequence[Tuple[int, int, int, int, int]], threads: int = None, engine: int = None) -> int:
     """jobs: (src_fd, src_offset, dst_fd, dst_offset, length).  Ranges of one file must not overlap.  -> bytes copied."""
     jobs = [j for j in jobs if j[4] > 0]
     if not jobs:
         return 0
     threads = threads or merge_threads()
+    engine = merge_engine() if engine is None else engine
     a = np.array(jobs, dtype=np.int64)
     try:
         from ._lib import lib
         fn = getattr(lib(), "s2s_copy_ranges", None)
     except (RuntimeError, OSError):
-        fn = None                                  # `merge-shards` on a host without the built library: the same calls from Python threads
+        fn = None                                  # `merge-shards` on a host without the built library: copy_file_range from Python
     if fn is not None:
         src, so, dst, do, ln = (np.ascontiguousarray(a[:, i], dtype=t) for i, t in
                                 enumerate((np.int32, np.int64, np.int32, np.int64, np.int64)))
-        got = fn(len(jobs), src.ctypes.data, so.ctypes.data, dst.ctypes.data, do.ctypes.data, ln.ctypes.data, int(threads))
+        got = fn(len(jobs), src.ctypes.data, so.ctypes.data, dst.ctypes.data, do.ctypes.data, ln.ctypes.data, int(threads), int(engine))
         if got < 0:
             raise OSError(f"s2s_copy_ranges failed ({got}: a bad argument, or -errno of the failing copy_file_range / pread / pwrite)")
         return int(got)
-    pieces = [(s, so + o, d, do + o, min(64 << 20, ln - o)) for s, so, d, do, ln in jobs for o in range(0, ln, 64 << 20)]
-
-    def one(p):
-        s, so, d, do, ln = p
+    for s_, so, d, do, ln in jobs:                 # one writer (see the module text)
         while ln > 0:
             try:
-                r = os.copy_file_range(s, d, ln, so, do)
+                r = os.copy_file_range(s_, d, min(ln, 1 << 30), so, do)
             except OSError:
-                r = os.pwrite(d, os.pread(s, min(ln, 8 << 20), so), do)
+                r = os.pwrite(d, os.pread(s_, min(ln, 8 << 20), so), do)
             if r <= 0:
                 raise OSError("short copy while merging shard files")
             so, do, ln = so + r, do + r, ln - r
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(one, pieces))
     return int(a[:, 4].sum())
 
 
@@ -187,7 +193,7 @@ def merge_blow5(paths: Sequence[str], out: str, threads: int = None, take_first:
         os.pwrite(dst, BLOW5_EOF, int(at[-1]))
     removing = remover.finish()
     return int(sum(counts)), {"bytes_copied": copied, "seconds": time.perf_counter() - t0, "scan_seconds": t_scan,
-                              "remove_seconds": removing, "threads": threads}
+                              "remove_seconds": removing, "threads": threads, "engine": "map" if merge_engine() else "fd"}
 
 
 def _slow5_header_end(fd: int, path: str) -> int:

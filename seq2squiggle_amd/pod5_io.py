@@ -824,7 +824,8 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
                 _write_tail(f, pa, meta, marker, file_identifier, sig_start, run_infos, cols, run_ids, pore_types)
         removing = remover.finish()
         merge_pod5.last = {"bytes_copied": int(copied), "seconds": time.perf_counter() - t0, "signal_rows": int(n),
-                           "batches_in_place": int(keep), "remove_seconds": removing, "threads": threads}
+                           "batches_in_place": int(keep), "remove_seconds": removing, "threads": threads,
+                           "engine": "map" if M.merge_engine() else "fd"}
         return len(cols["read_number"])
     finally:
         for s_ in shards:

@@ -573,7 +573,7 @@ _SHARD_SHAPES = [([5, 300, 102400, 102401, 250000, 17, 4000, 1, 64000], ((0, 3),
 
 @pytest.mark.parametrize("signal_compression", ["vbz", "none"])
 @pytest.mark.parametrize("shape", range(len(_SHARD_SHAPES)))
-def test_pod5_byte_range_merge_equals_the_read_by_read_merge(tmp_path, signal_compression, shape):
+def test_pod5_byte_range_merge_equals_the_read_by_read_merge(tmp_path, monkeypatch, signal_compression, shape):
     """merge_pod5 moves the signal rows as raw byte ranges (copy_file_range on threads) and re-batches the signal
     table by patching pyarrow's own message metadata -- the file must be BYTE FOR BYTE what handing every read of every shard to a
     fresh Pod5FileWriter produces (tests/_merge_serial.py: the merge of rounds 2-4), for VBZ and uncompressed signal tables, seams
@@ -590,10 +590,11 @@ def test_pod5_byte_range_merge_equals_the_read_by_read_merge(tmp_path, signal_co
     fid, marker = _uuid.uuid4(), _uuid.uuid4().bytes
     want = str(tmp_path / "want.pod5")
     n = serial.merge_pod5_rebuild(shards, want, fid, marker, signal_compression)
-    for threads in (1, 3):
+    for threads, engine in ((1, "fd"), (3, "map")):
+        monkeypatch.setenv("S2S_MERGE_ENGINE", engine)
         got = str(tmp_path / f"got{threads}.pod5")
         assert pod5_io.merge_pod5(shards, got, threads=threads, file_identifier=fid, section_marker=marker) == n == len(lens)
-        assert open(got, "rb").read() == open(want, "rb").read()
+        assert open(got, "rb").read() == open(want, "rb").read() and pod5_io.merge_pod5.last["engine"] == engine
     assert pod5_io.merge_pod5.last["signal_rows"] == sum(-(-int(x) // pod5_io.SIGNAL_CHUNK) for x in lens)
     # take_first: identity and marker are shard 0's
     own = pod5_io.read_pod5(shards[0])["footer"]["file_identifier"]
@@ -614,7 +615,7 @@ def test_pod5_byte_range_merge_equals_the_read_by_read_merge(tmp_path, signal_co
 
 
 @pytest.mark.parametrize("ext", ["blow5", "slow5"])
-def test_blow5_byte_range_merge_equals_the_record_by_record_merge(tmp_path, ext):
+def test_blow5_byte_range_merge_equals_the_record_by_record_merge(tmp_path, monkeypatch, ext):
     """The BLOW5 / SLOW5 merge copies each shard's record section as ONE range to its prefix-sum offset: byte-equal to the
     record-by-record copy of rounds 2-4; consume=True (first shard becomes the output) gives the same bytes and removes the shards;
     the record count comes from the size prefixes (s2s_blow5_scan) and doubles as the truncation check."""
@@ -626,7 +627,8 @@ def test_blow5_byte_range_merge_equals_the_record_by_record_merge(tmp_path, ext)
         shards = _write_shards(tmp_path, ext, lens, splits, rng, tag=f"s{k}")
         want = str(tmp_path / f"want{k}.{ext}")
         n = (serial.merge_blow5_serial if ext == "blow5" else serial.merge_slow5_serial)(shards, want)
-        for threads in (1, 4):
+        for threads, engine in ((1, "fd"), (4, "map")):
+            monkeypatch.setenv("S2S_MERGE_ENGINE", engine)
             got = str(tmp_path / f"got{k}_{threads}.{ext}")
             assert signal_io.merge_shards(shards, got, threads=threads) == n == 23
             assert open(got, "rb").read() == open(want, "rb").read()
@@ -646,9 +648,10 @@ def test_blow5_byte_range_merge_equals_the_record_by_record_merge(tmp_path, ext)
         assert not os.path.exists(tmp_path / "x.blow5") and not os.path.exists(tmp_path / "x.partial.blow5")
 
 
-def test_copy_ranges_native_and_python_agree(tmp_path):
-    """merge.copy_ranges: s2s_copy_ranges (copy_file_range on native threads, bounce-buffer fallback) and the Python-thread
-    fallback used when the library is absent put the same bytes in the same places; zero-length jobs are ignored."""
+def test_copy_ranges_engines_and_python_agree(tmp_path):
+    """merge.copy_ranges: both engines of s2s_copy_ranges (copy_file_range on descriptors; posix_fallocate + memcpy between shared
+    mappings on several threads) and the Python fallback used when the library is absent put the same bytes in the same places;
+    zero-length jobs are ignored; unaligned offsets and a destination hull that starts inside a page are fine."""
     from seq2squiggle_amd import merge as M
     rng = np.random.default_rng(3)
     src = tmp_path / "src.bin"
@@ -656,13 +659,13 @@ def test_copy_ranges_native_and_python_agree(tmp_path):
     src.write_bytes(data)
     spans = [(0, 10), (10, 0), (100_000, 1_234_567), (2_999_000, 1000), (5, 70_000)]
     want = bytearray(4_000_000)
-    at, jobs_of = 17, []
+    at, jobs_of = 4099, []
     for so, ln in spans:
         want[at:at + ln] = data[so:so + ln]
         jobs_of.append((so, at, ln))
         at += ln + 3
     outs = []
-    for name, hide in (("native", False), ("python", True)):
+    for name, hide, engine in (("fd", False, 0), ("map", False, 1), ("python", True, None)):
         fs, fd = os.open(src, os.O_RDONLY), os.open(tmp_path / f"{name}.bin", os.O_RDWR | os.O_CREAT)
         os.ftruncate(fd, len(want))
         if hide:
@@ -670,14 +673,14 @@ def test_copy_ranges_native_and_python_agree(tmp_path):
             real = LB.lib
             LB.lib = lambda: (_ for _ in ()).throw(RuntimeError("hidden"))
         try:
-            assert M.copy_ranges([(fs, so, fd, do, ln) for so, do, ln in jobs_of], threads=3) == sum(ln for _, ln in spans)
+            assert M.copy_ranges([(fs, so, fd, do, ln) for so, do, ln in jobs_of], threads=3, engine=engine) == sum(ln for _, ln in spans)
         finally:
             if hide:
                 LB.lib = real
             os.close(fs)
             os.close(fd)
         outs.append(open(tmp_path / f"{name}.bin", "rb").read())
-    assert outs[0] == outs[1] == bytes(want)
+    assert outs[0] == outs[1] == outs[2] == bytes(want)
 
 
 def test_predict_gpus_option_starts_one_rank_per_gpu():

@@ -278,7 +278,7 @@ def check_laws():
 
 
 L.s2s_copy_ranges.restype = i64
-L.s2s_copy_ranges.argtypes = [i32, vp, vp, vp, vp, vp, i32]
+L.s2s_copy_ranges.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32]
 L.s2s_blow5_scan.restype = i64
 L.s2s_blow5_scan.argtypes = [i32, i64, i64]
 
@@ -309,9 +309,12 @@ def check_merge_helpers(threads):
         os.ftruncate(dst, at)
         cols = [Buf(np.array([j[i] for j in jobs], dt).tobytes()) for i, dt in ((0, np.int32), (1, np.int64), (2, np.int64), (3, np.int64))]
         dfd = Buf(np.full(n, dst, np.int32).tobytes())
-        got = L.s2s_copy_ranges(n, cols[0].p, cols[1].p, dfd.p, cols[2].p, cols[3].p, threads)
-        assert got == sum(j[3] for j in jobs), got
-        assert os.pread(dst, at, 0) == bytes(want)
+        for engine in (0, 1):                              # descriptors; preallocate + mapped copy
+            os.ftruncate(dst, 0)
+            os.ftruncate(dst, at)
+            got = L.s2s_copy_ranges(n, cols[0].p, cols[1].p, dfd.p, cols[2].p, cols[3].p, threads, engine)
+            assert got == sum(j[3] for j in jobs), (engine, got)
+            assert os.pread(dst, at, 0) == bytes(want), engine
         for b in cols + [dfd]:
             b.free()
         # record chain

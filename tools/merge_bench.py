@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Throughput of the rank-shard merge (seq2squiggle_amd/merge.py, pod5_io.merge_pod5) on this host: N synthetic shard files of
-`--gb` GB in all (uncompressed records / signal rows, written by the product's writers) on `--dir`, merged with 1..T copy
-threads (s2s_copy_ranges: copy_file_range on descriptors), plain and with consume (first shard becomes the output, the others are
-deleted as they are consumed).  (Commit 1b15c95 also had a mapped-memcpy engine: profiles/r05/merge_bench_*_mapped_vs_fd.txt.)  No GPU.     python tools/merge_bench.py [--gb 4] [--shards 8] [--dir /dev/shm]"""
+`--gb` GB in all (uncompressed records / signal rows, written by the product's writers) on `--dir`, merged through both engines of
+s2s_copy_ranges (map: posix_fallocate + memcpy between shared mappings on 1..T threads; fd: copy_file_range, one writer), plain and
+with consume (first shard becomes the output, the others are deleted as they are consumed).  No GPU.     python tools/merge_bench.py [--gb 4] [--shards 8] [--dir /dev/shm]"""
 import argparse
 import logging
 import os
@@ -22,7 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gb", type=float, default=4.0)
 ap.add_argument("--shards", type=int, default=8)
 ap.add_argument("--dir", default="/dev/shm")
-ap.add_argument("--threads", default="1,2,4")
+ap.add_argument("--threads", default="1,4,8,16")
 a = ap.parse_args()
 prof = U.get_profile("dna-r10-prom")
 tmp = tempfile.mkdtemp(dir=a.dir)
@@ -54,8 +54,9 @@ try:
         total = sum(os.path.getsize(p) for p in shards)
         print(f"{ext}: {a.shards} shards, {total / 1e9:.2f} GB on {a.dir}", flush=True)
         out = os.path.join(tmp, "m." + ext)
-        for how in ("fd",):
-            for th in [int(x) for x in a.threads.split(",")]:
+        for how in ("map", "fd"):
+            os.environ["S2S_MERGE_ENGINE"] = how
+            for th in ([int(x) for x in a.threads.split(",")] if how == "map" else [1]):
                 best = None
                 for _ in range(2):
                     if os.path.exists(out):
@@ -66,12 +67,13 @@ try:
                     best = dt if best is None else min(best, dt)
                 print(f"  {how:3s} threads {th:2d}: {n} records, {best:.3f} s, {total / best / 1e9:.2f} GB/s", flush=True)
         os.remove(out)
-        th = 1
+        os.environ.pop("S2S_MERGE_ENGINE", None)
+        th = None
         t = time.perf_counter()
         n = signal_io.merge_shards(shards, out, threads=th, consume=True)
         dt = time.perf_counter() - t
         st = signal_io.merge_shards.last
-        print(f"  consume, threads {th}: {n} records, {dt:.3f} s in all (removing the shards beside the copy: {st.get('remove_seconds', 0):.3f} s of unlink), "
+        print(f"  consume, engine {st.get('engine')}, threads {st.get('threads')}: {n} records, {dt:.3f} s in all (removing the shards beside the copy: {st.get('remove_seconds', 0):.3f} s of unlink), "
               f"{total / dt / 1e9:.2f} GB/s of output; {st['bytes_copied'] / 1e9:.2f} GB moved", flush=True)
         os.remove(out)
 finally:

@@ -4,6 +4,8 @@
   append: N processes appending 32 MiB blocks to ONE file opened O_APPEND          (one shared output file)
   mapped: N processes storing 32 MiB blocks into THEIR region of ONE file through a shared mapping (no inode lock)
   pwrite: N processes pwrite()-ing 32 MiB blocks into THEIR region of ONE file     (inode lock per call)
+  mapped+ / pwrite+: the same two into a file whose pages were allocated BEFOREHAND (posix_fallocate, timed on its own): what a
+          join costs if the destination is pre-faulted while the ranks still compute
   anon  : N threads of numpy copies in anonymous memory                           (the memory system, no file system)
 python tools/probes/fs_write_probe.py [dir=/dev/shm] [GB per case=4]"""
 import os
@@ -34,7 +36,7 @@ def region_writer(path, kind, idx, nblk, barrier, q):
     buf = np.random.default_rng(os.getpid()).integers(0, 255, BLK, dtype=np.uint8)
     fd = os.open(path, os.O_RDWR)
     base = idx * nblk * BLK
-    mm = mmap.mmap(fd, 0) if kind == "mapped" else None
+    mm = mmap.mmap(fd, 0) if kind.startswith("mapped") else None
     view = np.frombuffer(mm, np.uint8) if mm is not None else None
     barrier.wait()
     t = time.perf_counter()
@@ -57,6 +59,13 @@ def run_region(kind, n):
     path = os.path.join(d, f"probe_{os.getpid()}_r")
     with open(path, "wb") as f:
         f.truncate(per * n * BLK)
+        if kind.endswith("+"):
+            t = time.perf_counter()
+            os.posix_fallocate(f.fileno(), 0, per * n * BLK)
+            dt = time.perf_counter() - t
+            if n == 1:
+                print(f"fallocate: {per * n * BLK / 1e9:.2f} GB in {dt:.2f} s = {per * n * BLK / dt / 1e9:.2f} GB/s", flush=True)
+    kind = kind.rstrip("+") if False else kind
     barrier, q = mp.Barrier(n + 1), mp.Queue()
     ps = [mp.Process(target=region_writer, args=(path, kind, i, per, barrier, q)) for i in range(n)]
     for p in ps:
@@ -118,6 +127,6 @@ if __name__ == "__main__":
     for kind in ("own", "append"):
         for n in (1, 2, 4, 8):
             run(kind, n)
-    for kind in ("mapped", "pwrite"):
+    for kind in ("mapped", "pwrite", "mapped+", "pwrite+"):
         for n in (1, 2, 4, 8):
             run_region(kind, n)
