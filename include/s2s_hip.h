@@ -279,10 +279,12 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
  * s2s_copy_ranges copies n byte ranges (src_fd[i], src_off[i], len[i]) -> (dst_fd[i], dst_off[i]); ranges must not overlap inside
  * one file.  engine 0: copy_file_range on the descriptors (in the kernel, no user-space buffer; pread / pwrite through a bounce
  * buffer where the file system refuses it), ONE writer whatever `threads` says -- buffered writes of one file take its inode lock and
- * more writers are slower (profiles/r05/fs_write_probe_shm.txt: 6.5 GB/s with one, 3.2-4.1 GB/s with 2-8).  engine 1: the
- * destination ranges are allocated first (posix_fallocate: 18.6 GB/s on that box) and then filled by memcpy between shared
- * mappings on `threads` threads (stores into existing pages take no lock: 20 GB/s with 8); when the file system refuses the
- * allocation or a mapping, engine 0 runs instead.  Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the failing call).
+ * more writers are slower (profiles/r05/fs_write_probe_shm.txt: 6.5 GB/s with one, 3.2-4.1 GB/s with 2-8).  engine 1: where the
+ * destination is on tmpfs, its ranges are allocated first (posix_fallocate: 18.6 GB/s on that box) and then filled on `threads`
+ * threads, each pread()ing the source into a populated shared mapping of the destination (pages that exist: no lock, no
+ * allocation; 8.0 against 5.7 GB/s for engine 0); any other file system, a refused allocation or mapping: engine 0.  engine 2: the
+ * same on any file system (A/B: it loses on a disk's page cache).  Returns the bytes copied, or < 0 (S2S_ERR_ARG, or -errno of the
+ * failing call; -EIO when a source is shorter than its range).
  * s2s_blow5_scan walks the [u64 size][body] records of a BLOW5 file between byte offsets begin and end (the end of the
  * header and the start of the end-of-file marker) reading the size prefixes only: the record count, or -2 when the chain of
  * sizes does not end exactly at `end` (a truncated shard). */

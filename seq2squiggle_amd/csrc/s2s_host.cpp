@@ -911,6 +911,7 @@ extern "C" int64_t s2s_fastq_clean(const uint8_t* data, int64_t n, int32_t map_a
 #include <map>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 
 namespace {
@@ -946,21 +947,25 @@ int64_t copy_one(int src, int64_t src_off, int dst, int64_t dst_off, int64_t len
 //  * descriptors (engine 0): copy_file_range, in the kernel.  One destination file has ONE fast writer this way: buffered writes
 //    take its inode lock, so 2-8 threads into the SAME file are slower than one (3.2-4.1 against 6.5 GB/s on the MI355X box's tmpfs,
 //    profiles/r05/fs_write_probe_shm.txt), and what a lone writer spends its time on is allocating the destination's pages.
-//  * preallocate + mapped copy (engine 1): posix_fallocate() the destination ranges first -- allocation WITHOUT data runs at 18.6 GB/s
-//    there -- then memcpy between shared mappings of the files on `threads` threads: stores into pages that already exist take
-//    no lock and no allocation and scale with the memory system (20 GB/s with 8 writers against 10 GB/s for a lone pwrite into the
-//    same preallocated file).  The space is reserved before the first store, so a full file system is an error code (the fallocate
-//    fails, engine 0 takes over and reports ENOSPC), never a SIGBUS.  Round 5's first mapped engine (commit 1b15c95) stored into
-//    pages that did NOT exist yet and lost to copy_file_range everywhere: the page allocation under the faults was the bound.
+//  * preallocate + mapped fill (engine 1, tmpfs destinations): posix_fallocate() the destination ranges first -- allocation WITHOUT
+//    data runs at 18.6 GB/s there -- then `threads` threads each map-populate a 16-MiB piece of the destination (MADV_POPULATE_WRITE:
+//    one call instead of a trap per page) and pread() the source straight into it: the kernel copies from the source's page cache
+//    into pages that already exist -- no inode lock, no allocation.  8.0 GB/s against 5.7 GB/s for engine 0 on the same box
+//    (profiles/r05/merge_bench_shm.txt; memcpy from a source mapping instead of pread: 6.1; without the populate call: 6.7; with the
+//    next range's fallocate running beside the copy: 4.0 -- it slows the faults down).  The space is reserved before the first store,
+//    so a full file system is an error code (the fallocate fails, engine 0 takes over and reports ENOSPC), never a SIGBUS.  On a
+//    disk file system's page cache the same engine LOSES (3.7-4.5 against 7-10 GB/s: fallocate is a block allocation there), so
+//    engine 1 is only taken for tmpfs.  (Round 5's first mapped engine, commit 1b15c95, stored into pages that did NOT exist yet and
+//    lost everywhere: the page allocation under the faults was the bound.)
 namespace {
 struct Span { int64_t lo = INT64_MAX, hi = 0; uint8_t* base = nullptr; size_t bytes = 0; };      // the hull of a file's ranges, and its mapping
 
-bool map_spans(std::map<int, Span>& spans, bool writable) {
+bool map_spans(std::map<int, Span>& spans) {
     for (auto& kv : spans) {
         Span& sp = kv.second;
         sp.lo &= ~(int64_t)4095;                                     // (mmap wants a page-aligned file offset)
         sp.bytes = (size_t)(sp.hi - sp.lo);
-        void* m = mmap(nullptr, sp.bytes, writable ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, kv.first, (off_t)sp.lo);
+        void* m = mmap(nullptr, sp.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, kv.first, (off_t)sp.lo);
         if (m == MAP_FAILED) { sp.base = nullptr; return false; }
         sp.base = static_cast<uint8_t*>(m);
     }
@@ -974,40 +979,37 @@ void unmap_spans(std::map<int, Span>& spans) {
 
 extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd,
                                    const int64_t* dst_off, const int64_t* len, int32_t threads, int32_t engine) {
-    if (n < 0 || threads < 1 || engine < 0 || engine > 1 || (n > 0 && (!src_fd || !src_off || !dst_fd || !dst_off || !len))) return S2S_ERR_ARG;
+    if (n < 0 || threads < 1 || engine < 0 || engine > 2 || (n > 0 && (!src_fd || !src_off || !dst_fd || !dst_off || !len))) return S2S_ERR_ARG;
     // pieces of <= 16 MiB, so that one long range does not leave the other threads idle
     struct Piece { int src, dst; int64_t so, d_o, len; };
     std::vector<Piece> pieces;
     const int64_t cut = 16ll << 20;
     int64_t total = 0;
-    std::map<int, Span> srcs, dsts;
+    std::map<int, Span> dsts;
+    std::map<int, int64_t> src_end;
     for (int i = 0; i < n; ++i) {
         if (len[i] < 0 || src_off[i] < 0 || dst_off[i] < 0) return S2S_ERR_ARG;
         if (len[i] == 0) continue;
         for (int64_t o = 0; o < len[i]; o += cut)
             pieces.push_back({src_fd[i], dst_fd[i], src_off[i] + o, dst_off[i] + o, std::min(cut, len[i] - o)});
         total += len[i];
-        Span& a = srcs[src_fd[i]];
-        a.lo = std::min(a.lo, src_off[i]); a.hi = std::max(a.hi, src_off[i] + len[i]);
+        src_end[src_fd[i]] = std::max(src_end[src_fd[i]], src_off[i] + len[i]);
         Span& b = dsts[dst_fd[i]];
         b.lo = std::min(b.lo, dst_off[i]); b.hi = std::max(b.hi, dst_off[i] + len[i]);
     }
     if (pieces.empty()) return 0;
-    bool mapped = engine == 1;
+    bool mapped = engine >= 1;
     if (mapped)
         for (auto& kv : dsts) {
-            if (srcs.count(kv.first)) { mapped = false; break; }             // a file copied onto itself: descriptors
             struct stat st;
-            if (fstat(kv.first, &st) != 0 || !S_ISREG(st.st_mode)) { mapped = false; break; }
+            struct statfs fs;
+            if (src_end.count(kv.first) || fstat(kv.first, &st) != 0 || !S_ISREG(st.st_mode)) { mapped = false; break; }   // (a file copied onto itself: descriptors)
+            if (engine == 1 && (fstatfs(kv.first, &fs) != 0 || fs.f_type != 0x01021994)) { mapped = false; break; }       // TMPFS_MAGIC (engine 2: any file system, A/B)
             if (posix_fallocate(kv.first, (off_t)kv.second.lo, (off_t)(kv.second.hi - kv.second.lo)) != 0) { mapped = false; break; }
         }
     if (mapped) {
-        for (auto& kv : srcs) {                                              // (a source shorter than its ranges would fault: checked here)
-            struct stat st;
-            if (fstat(kv.first, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < kv.second.hi) { mapped = false; break; }
-        }
-        mapped = mapped && map_spans(srcs, false) && map_spans(dsts, true);
-        if (!mapped) { unmap_spans(srcs); unmap_spans(dsts); }
+        mapped = map_spans(dsts);
+        if (!mapped) unmap_spans(dsts);
     }
     std::atomic<size_t> next{0};
     std::atomic<int64_t> err{0};
@@ -1019,9 +1021,18 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
             if (i >= pieces.size() || err.load()) return;
             const Piece& p = pieces[i];
             if (mapped) {
-                const Span& a = srcs[p.src];
                 const Span& b = dsts[p.dst];
-                std::memcpy(b.base + (p.d_o - b.lo), a.base + (p.so - a.lo), (size_t)p.len);
+                uint8_t* to = b.base + (p.d_o - b.lo);
+#ifdef MADV_POPULATE_WRITE
+                const uintptr_t lo = (uintptr_t)to & ~(uintptr_t)4095, hi = ((uintptr_t)to + (uintptr_t)p.len + 4095) & ~(uintptr_t)4095;
+                (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE);        // (Linux 5.14+; refused elsewhere: plain faults)
+#endif
+                int64_t done = 0;
+                while (done < p.len) {                                       // a source shorter than its range ends the call with -EIO, no fault
+                    const ssize_t r = pread(p.src, to + done, (size_t)(p.len - done), (off_t)(p.so + done));
+                    if (r <= 0) { if (r < 0 && errno == EINTR) continue; err = r < 0 ? -errno : -EIO; break; }
+                    done += r;
+                }
                 continue;
             }
             const int64_t r = copy_one(p.src, p.so, p.dst, p.d_o, p.len, bounce, in_kernel);
@@ -1033,7 +1044,7 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
     for (int w = 1; w < workers; ++w) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
-    if (mapped) { unmap_spans(srcs); unmap_spans(dsts); }
+    if (mapped) unmap_spans(dsts);
     return err.load() < 0 ? err.load() : total;
 }
 

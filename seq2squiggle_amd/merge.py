@@ -9,10 +9,11 @@ table, the footers -- pod5_io.merge_pod5).
 What bounds it is how the file system lets ONE file be filled (profiles/r05/fs_write_probe_shm.txt, the MI355X box's tmpfs): a
 buffered writer (pwrite, copy_file_range) holds the inode lock and allocates the pages as it goes -- 6.5 GB/s, and 2-8 such
 writers of the same file are SLOWER (3.2-4.1 GB/s), while separate files scale to 42 GB/s, which is why the ranks write their own
-files.  But allocating the pages WITHOUT data (posix_fallocate) runs at 18.6 GB/s, and stores through a shared mapping into pages
-that already exist take no lock and scale with the memory system (20 GB/s with 8 writers).  Hence the default engine: reserve a
-shard's destination range, then memcpy it between mappings on several threads (engine "map"); `S2S_MERGE_ENGINE=fd` selects
-copy_file_range with one writer (what every file system supports; also the automatic fallback).
+files.  But allocating the pages WITHOUT data (posix_fallocate) runs at 18.6 GB/s, and filling pages that already exist through a
+shared mapping takes no lock and scales with threads.  Hence the default engine ("map"): on tmpfs reserve a shard's destination
+range, then fill it on merge_threads() threads -- 8.0 GB/s of output against 5.7 GB/s for copy_file_range with its one writer on
+the same box (profiles/r05/merge_bench_shm.txt); on any other file system (a disk's page cache: fallocate is a block allocation
+there, and the one writer does 7-10 GB/s) s2s_copy_ranges takes copy_file_range by itself.  `S2S_MERGE_ENGINE=fd` forces that.
 `take_first=True` turns the first shard INTO the output file (its payload is already where it belongs: 1/N fewer bytes move);
 `consume=True` deletes every other shard as soon as its bytes are in the output, on a helper thread beside the copy of the
 next one (freeing 6 GB of tmpfs pages takes 0.5 s, and the pages go straight back to the copy: the peak is the output + one shard,
@@ -29,9 +30,11 @@ BLOW5_EOF = b"5WOLB"
 
 
 def merge_engine() -> int:
-    """0: copy_file_range on descriptors, one writer; 1 (default): preallocate the destination range, then memcpy between shared
-    mappings on merge_threads() threads (falls back to 0 where the file system refuses).  S2S_MERGE_ENGINE = fd | map."""
-    return 0 if os.environ.get("S2S_MERGE_ENGINE", "map").lower().startswith("f") else 1
+    """0: copy_file_range on descriptors, one writer; 1 (default): on tmpfs preallocate the destination range, then fill it through a
+    shared mapping on merge_threads() threads (0 on other file systems or where refused); 2: that on any file system (A/B).
+    S2S_MERGE_ENGINE = fd | map | map-anywhere."""
+    want = os.environ.get("S2S_MERGE_ENGINE", "map").lower()
+    return 0 if want.startswith("f") else 2 if want.endswith("anywhere") else 1
 
 
 def merge_threads() -> int:

@@ -802,10 +802,10 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
             for k_, j_ in enumerate(jobs):
                 if j_[5] >= 0:
                     last_job_of[j_[5]] = k_
-            cut_after = sorted((k_, s_i) for s_i, k_ in last_job_of.items())
+            cut_after = sorted((k_, s_i) for s_i, k_ in last_job_of.items()) + [(len(jobs) - 1, None)]
             copied, start = 0, 0
             done_shards = set()
-            for k_, s_i in cut_after + [(len(jobs) - 1, None)]:
+            for k_, s_i in cut_after:
                 if k_ + 1 > start:
                     copied += M.copy_ranges([j_[:5] for j_ in jobs[start:k_ + 1]], threads)
                     start = k_ + 1

@@ -309,7 +309,7 @@ def check_merge_helpers(threads):
         os.ftruncate(dst, at)
         cols = [Buf(np.array([j[i] for j in jobs], dt).tobytes()) for i, dt in ((0, np.int32), (1, np.int64), (2, np.int64), (3, np.int64))]
         dfd = Buf(np.full(n, dst, np.int32).tobytes())
-        for engine in (0, 1):                              # descriptors; preallocate + mapped copy
+        for engine in (0, 2):                              # descriptors; preallocate + mapped fill (2: on any file system)
             os.ftruncate(dst, 0)
             os.ftruncate(dst, at)
             got = L.s2s_copy_ranges(n, cols[0].p, cols[1].p, dfd.p, cols[2].p, cols[3].p, threads, engine)
