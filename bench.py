@@ -448,8 +448,10 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
                 from seq2squiggle_amd.parallel import rank_output_path
                 from seq2squiggle_amd.signal_io import merge_shards
                 shards = [rank_output_path(os.path.join(rows[r][6], "o.blow5"), r, world) for r in range(world)]
+                # (the other ranks wait at the barrier below: rank 0 may use the node's CPU share for the fill, as the command's parent does)
+                threads = max(1, min(8, cpu_share() * int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
                 t1 = time.perf_counter()
-                n_rec = merge_shards(shards, os.path.join(td, "merged.blow5"), consume=True)
+                n_rec = merge_shards(shards, os.path.join(td, "merged.blow5"), threads=threads, consume=True)
                 merged = dict(merge_shards.last, seconds=time.perf_counter() - t1, records=n_rec)
             except Exception as e:
                 merged = {"error": f"{type(e).__name__}: {e}"}
@@ -477,10 +479,12 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
     if merged and "error" not in merged:
         out["merge_seconds"] = merged["seconds"]
         out["merge"] = {"bytes": merged.get("bytes"), "bytes_copied": merged.get("bytes_copied"), "threads": merged["threads"],
+                        "engine": merged.get("engine"),
                         "gb_per_sec": merged.get("bytes", 0) / merged["seconds"] / 1e9, "records": merged["records"],
                         "remove_seconds": merged.get("remove_seconds"),
-                        "how": "first rank file becomes the output, the record sections of the others move as byte ranges (copy_file_range, "
-                               "one writer: seq2squiggle_amd/merge.py), each rank file deleted as soon as it is in"}
+                        "how": "first rank file becomes the output, the record sections of the others move as byte ranges (tmpfs: the range "
+                               "is preallocated, then filled through a shared mapping on several threads; elsewhere copy_file_range with one "
+                               "writer: seq2squiggle_amd/merge.py), each rank file deleted as soon as it is in"}
         out["with_merge"] = {"seconds": wall + merged["seconds"], "chunks_per_sec": total / (wall + merged["seconds"]),
                              "reads_per_sec": n_total / (wall + merged["seconds"])}
     elif merged:

@@ -130,7 +130,12 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
         timing["total_seconds"] = time.time() - t0
         try:
             import resource
-            timing["parent_peak_rss_mb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0      # the join keeps no payload in memory
+            # (the peak counts the tmpfs pages of the output while they are mapped for the fill -- one shard's span, shared memory that
+            #  belongs to the file, not to this process; what the process itself holds is the anonymous part)
+            timing["parent_peak_rss_mb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+            for line in open("/proc/self/status"):
+                if line.startswith("RssAnon:"):
+                    timing["parent_anon_rss_mb"] = int(line.split()[1]) / 1024.0
         except (ImportError, OSError):
             pass
         if os.environ.get("S2S_TIMING_JSON") and not os.environ.get("S2S_DRY_LAUNCH"):
