@@ -5,6 +5,7 @@ import os
 from ._build import LIB as _LIB_DEFAULT
 
 _lib = None
+loaded_before_torch = False
 
 
 class S2SConfig(C.Structure):
@@ -39,6 +40,9 @@ def lib():
     if not os.path.exists(LIB):
         raise RuntimeError(f"HIP extension not built: {LIB} is missing (run __graft_entry__.build()); "
                            "there is no CPU fallback for the predict path")
+    import sys
+    global loaded_before_torch
+    loaded_before_torch = "torch" not in sys.modules      # fine for the host-side entry points (the `--gpus N` parent, merge-shards); see engine.py
     L = C.CDLL(LIB)
     vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
     lenient = "S2S_HIP_LIB" in os.environ     # an explicitly selected variant (A/B against an older build): entry points it lacks stay unbound

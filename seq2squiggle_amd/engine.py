@@ -63,7 +63,11 @@ class Engine:
             torch.cuda.current_stream().synchronize()
             rc = L.s2s_create(C.byref(ccfg), blob.ctypes.data_as(C.c_void_p), blob.nbytes, self.device_index, C.byref(h))
         if rc != 0:
-            raise ValueError(f"s2s_create failed ({rc}): {L.s2s_last_error(None).decode()}")
+            hint = ""
+            if rc == -2 and _lib.loaded_before_torch:      # S2S_ERR_HIP with the library bound to another HIP runtime than torch's
+                hint = (" -- libs2s_hip.so was loaded BEFORE torch in this process (it then binds to /opt/rocm's libamdhip64 instead of the "
+                        "one torch bundles, and sees no device): import torch first")
+            raise ValueError(f"s2s_create failed ({rc}): {L.s2s_last_error(None).decode()}{hint}")
         self._h = h
         if os.environ.get("S2S_PROFILE_KERNEL"):          # diagnostic: HIP events around every predict launch, summed up at close()
             self.set_profiling(True)
