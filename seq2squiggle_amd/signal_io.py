@@ -461,7 +461,9 @@ def merge_shards(paths, out: str, threads: int = None, consume: bool = False) ->
     except BaseException:
         if take_first and os.path.exists(tmp) and not os.path.exists(paths[0]):
             # the first shard had already become the partial output: it is no shard any more, say where the bytes are
-            logger.error(f"merge failed after {paths[0]} was taken over as {tmp}; the other shard files are untouched")
+            left = [p_ for p_ in paths[1:] if os.path.exists(p_)]
+            logger.error(f"merge failed after {paths[0]} had been taken over as {tmp}: that file holds the records of the shards consumed "
+                         f"so far (it has no valid end yet); still on disk, untouched: {', '.join(left) or 'none'}")
         elif os.path.exists(tmp):
             os.remove(tmp)
         raise
