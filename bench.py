@@ -458,6 +458,9 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
             shutil.rmtree(td, ignore_errors=True)              # (room for the command below)
             os.makedirs(td, exist_ok=True)
             command = one_command(mode, world, n_total, fasta, td)
+            if "seconds" in command:                       # ... and with the join running WHILE the ranks compute (another record order)
+                os.remove(os.path.join(td, "cmd.blow5"))
+                command["join_live"] = one_command(mode, world, n_total, fasta, td, join="live")
         dist.barrier(group=grp)                                # nobody removes a rank file before rank 0 has joined them
     finally:
         shutil.rmtree(td, ignore_errors=True)
@@ -492,12 +495,13 @@ def end_to_end_sharded(mode, dist, rank, world, dev):
     if command:
         out["one_command"] = command
         out["launch_seconds"] = command.get("launch_seconds")
-        if "seconds" in command:
-            command["chunks_per_sec"] = total / command["seconds"]
+        for c_ in (command, command.get("join_live", {})):
+            if "seconds" in c_:
+                c_["chunks_per_sec"] = total / c_["seconds"]
     return out
 
 
-def one_command(mode, world, n_total, fasta, td):
+def one_command(mode, world, n_total, fasta, td, join="after"):
     """The command people run: `python -m seq2squiggle_amd predict <lambda> -n N -r 5000 -o OUT.blow5 --gpus <world>` as a child of
     rank 0, started while the bench's own ranks wait at a barrier (two processes per GPU for its duration): wall clock of the
     whole command with its own account of launch (spawn -> the slowest rank has the interpreter, torch and the library loaded),
@@ -514,7 +518,7 @@ def one_command(mode, world, n_total, fasta, td):
         env["S2S_ONE_GPU"] = "1"
     cmd = [sys.executable, "-m", "seq2squiggle_amd", "predict", fasta, "-n", str(n_total), "-r", "5000", "-o",
            os.path.join(td, "cmd.blow5"), "--gpus", str(world), "--seed", "42", "-m",
-           os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"), "--compute-mode", mode, "-v", "warning"]
+           os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"), "--compute-mode", mode, "-v", "warning"] + (["--join", join] if join != "after" else [])
     t0 = time.perf_counter()
     try:
         p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
@@ -527,7 +531,7 @@ def one_command(mode, world, n_total, fasta, td):
            "reads_per_sec": n_total / seconds, "output_bytes": os.path.getsize(os.path.join(td, "cmd.blow5"))}
     try:
         with open(env["S2S_TIMING_JSON"]) as f:
-            out.update({k: v for k, v in json.load(f).items() if k.endswith("_seconds") or k in ("merge_bytes", "merge_bytes_copied", "reads")})
+            out.update({k: v for k, v in json.load(f).items() if k.endswith("_seconds") or k in ("merge_bytes", "merge_bytes_copied", "reads", "join", "live_bytes", "join_order")})
     except (OSError, ValueError):
         pass
     return out
@@ -732,9 +736,9 @@ def main():
             out["end_to_end_sharded"] = sharded
             if "chunks_per_sec" in sharded:
                 out["end_to_end_sharded"]["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
-                for part in ("with_merge", "one_command"):         # ... with the merge into ONE file, and as the one command with its launch
-                    if "chunks_per_sec" in sharded.get(part, {}):
-                        sharded[part]["of_resident_rate"] = sharded[part]["chunks_per_sec"] / chunks_s
+                for part in (sharded.get("with_merge", {}), sharded.get("one_command", {}), sharded.get("one_command", {}).get("join_live", {})):
+                    if "chunks_per_sec" in part:                    # ... with the merge into ONE file, and as the one command with its launch
+                        part["of_resident_rate"] = part["chunks_per_sec"] / chunks_s
         if one_gpu:
             out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 (gloo barrier) -- NOT a scaling measurement"
         if world == 1 and not a.no_cpu_baseline:

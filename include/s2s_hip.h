@@ -291,6 +291,10 @@ int64_t s2s_fasta_clean(const uint8_t* data, int64_t n, int32_t map_acgtn, uint8
 int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64_t* src_off, const int32_t* dst_fd, const int64_t* dst_off,
                         const int64_t* len, int32_t threads, int32_t engine);
 int64_t s2s_blow5_scan(int32_t fd, int64_t begin, int64_t end);
+/* ... and over a file that is still growing (the live join, seq2squiggle_amd/merge.py: LiveJoin): the complete records from `begin`
+ * that end at or before `limit` (the file's size now), at most max_records; *out_end = the offset behind the last of them.  An
+ * incomplete record (or the 5-byte end marker) ends the walk without an error.  Returns the number of records, or S2S_ERR_ARG. */
+int64_t s2s_blow5_scan_upto(int32_t fd, int64_t begin, int64_t limit, int64_t max_records, int64_t* out_end);
 
 /* Which softmax path the split-f16 decoder attention (S2S_MODE_F16X3 / S2S_MODE_F16) runs (layers.py:20-40 is one unmasked
  * softmax over 250 keys; both paths compute it within the parity bound, with the same error against an fp64 evaluation):

@@ -28,7 +28,7 @@ class S2SDebug(C.Structure):
 EXPORTS = ("s2s_blob_floats", "s2s_create", "s2s_destroy", "s2s_last_error", "s2s_predict_chunks", "s2s_predict_packed",
            "s2s_export_reads", "s2s_svb_encode", "s2s_philox_u32", "s2s_set_profiling", "s2s_get_kernel_ms", "s2s_stats_read", "s2s_set_attention_path", "s2s_get_attention_path", "s2s_diag_read",
            "s2s_blow5_pack_bound", "s2s_blow5_pack", "s2s_compress_rows", "s2s_sampler_replay", "s2s_sampler_replay_law", "s2s_length_law",
-           "s2s_fasta_count", "s2s_fasta_clean", "s2s_fastq_clean", "s2s_copy_ranges", "s2s_blow5_scan", "s2s_attention_redo_threshold")
+           "s2s_fasta_count", "s2s_fasta_clean", "s2s_fastq_clean", "s2s_copy_ranges", "s2s_blow5_scan", "s2s_blow5_scan_upto", "s2s_attention_redo_threshold")
 
 
 def lib():
@@ -82,6 +82,7 @@ def lib():
     bind("s2s_fasta_clean", i64, [vp, i64, i32, vp, vp, vp, i64])
     bind("s2s_copy_ranges", i64, [i32, vp, vp, vp, vp, vp, i32, i32])
     bind("s2s_blow5_scan", i64, [i32, i64, i64])
+    bind("s2s_blow5_scan_upto", i64, [i32, i64, i64, i64, C.POINTER(i64)])
     bind("s2s_attention_redo_threshold", C.c_double, [])
     _lib = L
     return L

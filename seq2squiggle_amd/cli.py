@@ -89,12 +89,16 @@ def version():
                    "(the same as starting the command under torchrun --nproc-per-node N).")
 @click.option("--keep-shards", is_flag=True, hidden=True,
               help="With --gpus N: leave the OUT.rankN files as they are instead of merging them into OUT.")
+@click.option("--join", "join_mode", default="after", type=click.Choice(["after", "live"]), hidden=True,
+              help="With --gpus N: after = the rank files are joined in rank order once the ranks are done (the layout of a single-process "
+                   "file); live = the parent copies complete records / signal batches into OUT while the ranks run (round robin over the "
+                   "ranks: same reads, another record order; .blow5 and .pod5).")
 @click.pass_context
 def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profile, show_advanced_options, noise_sampler,
             duration_sampler, dwell_mean, dwell_std, noise_std, distr, predict_batch_size, export_every_n_samples,
             sample_rate, bps, digitisation, range_val, offset_mean, offset_std, median_before_mean, median_before_std,
             min_noise, min_duration, min_read_len, preserve_read_ids, seed, model, config, verbosity, compute_mode, attention_path,
-            gpus, keep_shards):
+            gpus, keep_shards, join_mode):
     """Generate nanopore signals from a reference genome (default) or from reads (--read-input)."""
     import os
     if gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -107,9 +111,38 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
             raise FileExistsError(f"{out} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
         import time
         t0 = time.time()
-        rc, timing, reap = _launch_ranks(gpus)
+        live = None
+        if join_mode == "live" and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
+            if not str(out).endswith((".blow5", ".pod5")):
+                raise click.UsageError("--join live handles .blow5 and .pod5 outputs")
+            from .merge import LiveJoin
+            from .parallel import rank_output_path
+            ext = os.path.splitext(str(out))[1]
+            partial = str(out)[:len(str(out)) - len(ext)] + ".partial" + ext
+            shard_paths = [rank_output_path(str(out), r, gpus) for r in range(gpus)]
+            for stale in [partial] + shard_paths:           # (a rank file left by an earlier run must not be mistaken for this run's)
+                if os.path.exists(stale):
+                    os.remove(stale)
+            live = LiveJoin(shard_paths, partial)
+        rc, timing, reap = _launch_ranks(gpus, live)
         timing["ranks_seconds"] = time.time() - t0
-        if rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
+        if live is not None:
+            if rc == 0:
+                t1 = time.time()
+                try:
+                    n, st = live.finish(consume=True)
+                    os.replace(live.out, str(out))
+                except BaseException:
+                    live.abort()
+                    raise
+                timing.update(merge_seconds=time.time() - t1, merge_bytes=st["bytes"], merge_bytes_copied=st["bytes"], reads=n, join="live",
+                              live_bytes=st["live_bytes"], live_copy_seconds=st["copy_seconds"], join_order=st["order"])
+                click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {round(timing.get('launch_seconds', 0), 2)} s, ranks "
+                           f"{timing['ranks_seconds']:.2f} s in all with {st['live_bytes'] / 1e9:.2f} of {st['bytes'] / 1e9:.2f} GB joined meanwhile, "
+                           f"{timing['merge_seconds']:.2f} s to finish the file; {st['order']}]")
+            else:
+                live.abort()
+        elif rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
             # one output file, as the reference writes (inference.py:65-79): the first rank's file becomes OUT, the payload of the
             # others moves in as byte ranges on copy threads (merge.py), the rank files are gone afterwards
             from .parallel import rank_output_path
@@ -179,14 +212,15 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
         os.replace(stamp + ".tmp", stamp)      # (appears whole: the parent starts the merge when it sees every rank's)
 
 
-def _launch_ranks(gpus: int):
+def _launch_ranks(gpus: int, live=None):
     """`predict --gpus N` outside torchrun: the same command line once per GPU, as N CHILD processes of this one (which never touches
     the GPU) with the environment torchrun would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1,
     MASTER_PORT) -- started directly: the elastic agent of torch.distributed.run costs an import of torch in the parent and a
     rendezvous before the first rank starts, and there is nothing here for it to supervise.  The first rank that fails ends the
     others (by their pids).  S2S_DRY_LAUNCH=1 prints the child command and environment instead of running it.
     -> (exit code, {"launch_seconds": spawn -> the slowest rank is ready to read its input, "predict_seconds": ... -> the slowest is
-    done}, reap): returns as soon as every rank's output file is complete and closed; reap() collects the processes afterwards."""
+    done}, reap): returns as soon as every rank's output file is complete and closed; reap() collects the processes afterwards.
+    live (merge.LiveJoin): its step() runs in the waiting loop, so that the rank files are joined while they grow."""
     import json
     import os
     import shutil
@@ -251,7 +285,11 @@ def _launch_ranks(gpus: int):
         left = set(range(gpus))
         # a rank writes its stamp when its output file is complete and closed (end of `predict`): once every rank has, the files
         # can be joined -- the processes may still be tearing down
-        while left and sum(f.endswith(".json") for f in os.listdir(timing_dir)) < gpus:
+        while left:
+            stamped = {f for f in os.listdir(timing_dir) if f.endswith(".json")}
+            if len(stamped) >= gpus:
+                break
+            moved = live is not None and live.step([f"rank{r}.json" in stamped for r in range(gpus)])   # (--join live: copy what is complete)
             for r in sorted(left):
                 code = procs[r].poll()
                 if code is None:
@@ -262,8 +300,8 @@ def _launch_ranks(gpus: int):
                     logger.error(f"rank {r} exited with code {code}; ending the other ranks")
                     for q in left:
                         procs[q].terminate()
-            if left:
-                time.sleep(0.01)
+            if left and not moved:
+                time.sleep(0.005)
     except BaseException:
         for p_ in procs:
             if p_.poll() is None:

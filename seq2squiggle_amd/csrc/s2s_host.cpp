@@ -1060,3 +1060,21 @@ extern "C" int64_t s2s_blow5_scan(int32_t fd, int64_t begin, int64_t end) {
     }
     return n;
 }
+
+// The same walk over a file that is still being written (the live join tails the rank files while the ranks run): complete records
+// only -- a size prefix or a body that reaches past `limit` (the file's size at the moment of the call) ends the walk without an
+// error -- and at most max_records of them.  *out_end = the byte offset behind the last complete record.
+extern "C" int64_t s2s_blow5_scan_upto(int32_t fd, int64_t begin, int64_t limit, int64_t max_records, int64_t* out_end) {
+    if (fd < 0 || begin < 0 || !out_end) return S2S_ERR_ARG;
+    int64_t pos = begin, n = 0;
+    while (n < max_records && limit - pos >= 8) {
+        uint64_t size;
+        if (pread(fd, &size, 8, (off_t)pos) != 8) break;
+        if (size > (uint64_t)(limit - pos - 8)) break;                 // body not (yet) whole: the writer is in the middle of it, or this is the end marker
+        pos += 8 + (int64_t)size;
+        ++n;
+    }
+    *out_end = pos;
+    return n;
+}
+

@@ -249,3 +249,257 @@ def merge_slow5(paths: Sequence[str], out: str, threads: int = None) -> Tuple[in
             copied = copy_ranges([(fds[i], begins[i], dst, int(at[i]), ends[i] - begins[i]) for i in range(len(paths))], threads or merge_threads())
             n = sum(counting)
     return int(n), {"bytes_copied": copied, "seconds": time.perf_counter() - t0}
+
+
+# ------------------------------------------------------------------------------------------------------------- the live join
+class LiveJoin:
+    """The join WHILE the ranks run (`predict --gpus N --join live`): the parent tails the rank files -- whose writers know nothing
+    of it -- and copies every complete unit (BLOW5: a record; POD5: a full 100-row signal batch, whose Arrow message is position
+    independent and moves verbatim) into the output as it appears, so that the ONE file is all but finished when the ranks are:
+    the command costs max(compute, output / fill rate) instead of their sum.
+
+    The price is the ORDER of the payload: it cannot be the rank order (where rank 1's bytes go is not known before rank 0 has
+    finished), so it is a fixed round robin -- QUANTUM units of rank 0, of rank 1, ..., again -- that depends on the ranks'
+    record sequences only, never on timing: a rank that has fewer than a quantum ready is waited for unless it is done (then its
+    rest goes).  Same records, same ids, numbers and samples as the join after the fact; BLOW5 record order and POD5 signal-row
+    placement differ (the POD5 reads table stays in read order).  That is why `--join after` (rank order, byte-equal to a
+    single-process file's layout) stays the default.
+
+    What can be read from a file that is being written: a writer appends with plain write() calls, bytes below the size a reader
+    sees are final, and both formats frame their units with a length in front -- a unit is taken only when the file is long
+    enough to hold all of it (s2s_blow5_scan_upto; the Arrow message header).  BLOW5Writer drops and rewrites its 5-byte end
+    marker around every batch: 5 bytes never parse as the 8-byte size prefix of a record."""
+
+    QUANTUM = {"blow5": 256, "pod5": 4}          # (about 30-40 MB of payload per turn for 5-10 kb reads)
+
+    def __init__(self, paths: Sequence[str], out: str, threads: int = None, punch: bool = True):
+        self.paths, self.out, self.n = list(paths), out, len(paths)
+        self.kind = "pod5" if out.endswith(".pod5") else "blow5"
+        if not out.endswith((".pod5", ".blow5")):
+            raise ValueError("the live join handles .blow5 and .pod5 outputs (SLOW5 text: --join after)")
+        self.threads = threads or merge_threads()
+        self.q = self.QUANTUM[self.kind]
+        self.fds = [None] * self.n
+        self.pos = [None] * self.n               # next byte of shard r not yet taken (None: its header is not there yet)
+        self.ended = [False] * self.n            # POD5: the shard's full batches are all seen (end-of-stream or its partial batch reached)
+        self.exhausted = [False] * self.n
+        self.headers = [None] * self.n
+        self.turn = 0
+        self.out_fd, self.out_pos = None, 0
+        self.units, self.bytes_live, self.copy_seconds = 0, 0, 0.0
+        self.blocks, self.placed = [], [[] for _ in range(self.n)]      # POD5
+        self.head_len = None
+        self._punch = _Puncher() if punch else None
+
+    # ---- shard headers
+    def _open(self, r: int) -> bool:
+        if self.fds[r] is None:
+            try:
+                self.fds[r] = os.open(self.paths[r], os.O_RDWR)
+            except FileNotFoundError:
+                return False
+        if self.pos[r] is not None:
+            return True
+        fd = self.fds[r]
+        size = os.fstat(fd).st_size
+        if self.kind == "blow5":
+            if size < 68:
+                return False
+            head = os.pread(fd, 68, 0)
+            if head[:6] != b"BLOW5\x01":
+                raise ValueError(f"{self.paths[r]}: not a BLOW5 file")
+            hlen = struct.unpack_from("<I", head, 64)[0]
+            if size < 68 + hlen:
+                return False
+            self.headers[r] = (head[:64], os.pread(fd, hlen, 68))
+            self.pos[r] = 68 + hlen
+        else:
+            from . import pod5_io as P
+            if size < 24 + 16:
+                return False
+            head = os.pread(fd, 40, 0)
+            if head[:8] != P.SIGNATURE or head[24:30] != b"ARROW1":
+                raise ValueError(f"{self.paths[r]}: not a POD5 file of this writer")
+            cont, mlen = struct.unpack_from("<Ii", head, 32)
+            if cont != 0xFFFFFFFF or mlen <= 0:
+                raise ValueError(f"{self.paths[r]}: no schema message where the signal table starts")
+            if size < 40 + mlen:
+                return False
+            self.headers[r] = os.pread(fd, 40 + mlen, 0)               # signature, marker, Arrow magic, schema message (no body)
+            self.pos[r] = 40 + mlen
+        return True
+
+    def _start_output(self) -> bool:
+        if self.out_fd is not None:
+            return True
+        if not self._open(0):
+            return False
+        self.out_fd = os.open(self.out, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o644)
+        if self.kind == "blow5":
+            head, text = self.headers[0]
+            first = head + struct.pack("<I", len(text)) + text
+        else:
+            first = self.headers[0]
+            self.head_len = len(first) - 24
+        os.pwrite(self.out_fd, first, 0)
+        self.out_pos = len(first)
+        return True
+
+    # ---- one turn of the round robin: True = the turn is over (units taken, or nothing will ever come), False = wait
+    def _take(self, r: int, done: bool) -> bool:
+        if self.exhausted[r]:
+            return True
+        if not self._open(r):
+            if done:                                # a rank that ended without a file (it always writes one, even empty): let finish() say so
+                raise FileNotFoundError(f"{self.paths[r]}: the rank is done but its file is missing or has no header")
+            return False
+        fd = self.fds[r]
+        size = os.fstat(fd).st_size
+        begin = self.pos[r]
+        if self.kind == "blow5":
+            from ._lib import lib
+            import ctypes as C
+            end = C.c_int64(0)
+            got = int(lib().s2s_blow5_scan_upto(fd, begin, size, self.q, C.byref(end)))
+            if got < 0:
+                raise OSError(f"s2s_blow5_scan_upto failed ({got})")
+            end = int(end.value)
+            last = done and got < self.q
+            if got < self.q and not done:
+                return False
+            if last and end != size - len(BLOW5_EOF):
+                raise ValueError(f"{self.paths[r]}: the records do not end at the end-of-file marker (truncated shard?)")
+        else:
+            got, end, blocks = 0, begin, []
+            from . import pod5_io as P
+            while got < self.q and not self.ended[r]:
+                if size - end < 8:
+                    break
+                cont, mlen = struct.unpack("<Ii", os.pread(fd, 8, end))
+                if cont != 0xFFFFFFFF:
+                    raise ValueError(f"{self.paths[r]}: Arrow message without continuation marker at {end}")
+                if mlen == 0:                        # end of stream: the signal table is closed
+                    self.ended[r] = True
+                    break
+                if size - end < 8 + mlen:
+                    break
+                meta = os.pread(fd, 8 + mlen, end)
+                m = P._batch_message(meta, 0)
+                body = struct.unpack_from("<q", meta, m["body_len"])[0]
+                rows = struct.unpack_from("<q", meta, m["length"])[0]
+                if rows < P.SIGNAL_BATCH_ROWS:       # the shard's last, partial batch: its rows are laid out by the finish
+                    self.ended[r] = True
+                    break
+                if size - end < 8 + mlen + body:
+                    break
+                blocks.append((8 + mlen, body))
+                end += 8 + mlen + body
+                got += 1
+            last = self.ended[r] and got < self.q
+            if got < self.q and not self.ended[r]:
+                if done:
+                    raise ValueError(f"{self.paths[r]}: the signal table has no end (truncated shard?)")
+                return False
+        if got:
+            t = time.perf_counter()
+            copy_ranges([(fd, begin, self.out_fd, self.out_pos, end - begin)], self.threads)
+            self.copy_seconds += time.perf_counter() - t
+            if self.kind == "pod5":
+                at = self.out_pos
+                for meta_len, body in blocks:
+                    self.placed[r].append(len(self.blocks))
+                    self.blocks.append((at - 24, meta_len, 0, body))       # (Arrow block offsets count from the embedded file's start)
+                    at += meta_len + body
+            if self._punch is not None:
+                self._punch.punch(fd, begin, end)
+            self.out_pos += end - begin
+            self.pos[r] = end
+            self.units += got
+            self.bytes_live += end - begin
+        if last:
+            self.exhausted[r] = True
+        return True
+
+    def step(self, done: Sequence[bool]) -> bool:
+        """Copies what the round robin allows right now.  done[r]: rank r has closed its file.  -> True if anything moved."""
+        if not self._start_output():
+            return False
+        moved = False
+        while not all(self.exhausted):
+            before = self.units
+            if not self._take(self.turn, bool(done[self.turn])):
+                break
+            moved = moved or self.units > before
+            self.turn = (self.turn + 1) % self.n
+        return moved
+
+    def finish(self, consume: bool = True) -> Tuple[int, dict]:
+        """Every rank is done: the rest of the round robin, then what only the end can write (BLOW5: the end marker; POD5: the rows
+        behind every shard's last full batch, the tables, the footers).  -> (records / reads, stats)."""
+        t0 = time.perf_counter()
+        live_bytes = self.bytes_live
+        self.step([True] * self.n)
+        if not all(self.exhausted):
+            raise RuntimeError("live join: a rank file did not come to its end")
+        if self._punch is not None:
+            self._punch.finish()
+        if self.kind == "blow5":
+            same = lambda text: [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]
+            for p_, (head, text) in zip(self.paths[1:], self.headers[1:]):
+                if head != self.headers[0][0] or same(text) != same(self.headers[0][1]):
+                    raise ValueError(f"{p_}: header differs from {self.paths[0]} (another profile, compression or run?)")
+            os.pwrite(self.out_fd, BLOW5_EOF, self.out_pos)
+            os.ftruncate(self.out_fd, self.out_pos + len(BLOW5_EOF))
+            n = self.units
+            for fd in self.fds:
+                os.close(fd)
+            os.close(self.out_fd)
+            if consume:
+                for p_ in self.paths:
+                    os.remove(p_)
+        else:
+            from . import pod5_io as P
+            for fd in self.fds:
+                os.close(fd)
+            blocks = np.array(self.blocks, dtype=P._BLOCK) if self.blocks else np.zeros(0, P._BLOCK)
+            n = P.merge_pod5(self.paths, self.out, threads=self.threads, consume=consume,
+                             _live={"fd": self.out_fd, "blocks": blocks, "placed": self.placed, "msg_base": self.out_pos - 24,
+                                    "head_len": self.head_len})
+            os.close(self.out_fd)
+        stats = {"live_bytes": live_bytes, "bytes": os.path.getsize(self.out), "finish_seconds": time.perf_counter() - t0,
+                 "copy_seconds": self.copy_seconds, "units_live": self.units, "threads": self.threads,
+                 "engine": "map" if merge_engine() else "fd", "order": f"round robin, {self.q} {'records' if self.kind == 'blow5' else 'signal batches'} per rank and turn"}
+        return n, stats
+
+    def abort(self) -> None:
+        for fd in [f for f in self.fds if f is not None] + ([self.out_fd] if self.out_fd is not None else []):
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        if os.path.exists(self.out):
+            os.remove(self.out)
+
+
+class _Puncher:
+    """Frees the pages of a shard file behind the live join (fallocate PUNCH_HOLE | KEEP_SIZE on the whole pages of the range, on a
+    helper thread): the rank files are staging buffers then, and the peak is the output plus what is in flight, not twice the output."""
+
+    def __init__(self):
+        import ctypes as C
+        self.libc = C.CDLL(None, use_errno=True)
+        self.libc.fallocate.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64]
+        self.ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2s-punch")
+        self.pending = []
+
+    def punch(self, fd: int, lo: int, hi: int) -> None:
+        lo, hi = (lo + 4095) & ~4095, hi & ~4095
+        if hi > lo:
+            self.pending.append(self.ex.submit(self.libc.fallocate, fd, 3, lo, hi - lo))      # FALLOC_FL_KEEP_SIZE | FALLOC_FL_PUNCH_HOLE
+            if len(self.pending) > 256:
+                self.pending = [f for f in self.pending if not f.done()]
+
+    def finish(self) -> None:
+        for f in self.pending:
+            f.result()
+        self.ex.shutdown()

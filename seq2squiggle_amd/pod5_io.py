@@ -578,15 +578,16 @@ class _Shard:
         o, n = self.at[content_type]
         return pa.ipc.open_file(pa.BufferReader(pa.py_buffer(self.buf).slice(o, n)))
 
-    def signal_rows(self, vbz: bool):
+    def signal_rows(self, vbz: bool, skip_batches: int = 0):
         """-> (ids [n][16] u8, samples [n] u32, lens [n] i64 in bytes (VBZ) or int16 samples (uncompressed), pos [n] i64: file offset
-        of each row's data, offset of the first record batch in the file, its schema)."""
+        of each row's data) of the rows behind the first skip_batches record batches (the live join has copied those and may
+        have punched them out of the file)."""
         buf = self.buf
         start, length = self.at[CT_SIGNAL]
         blocks, _, _ = _arrow_blocks(buf, start, length)
         ids, counts, lens, pos = [], [], [], []
         width = 1 if vbz else 2
-        for b in blocks:
+        for b in blocks[skip_batches:]:
             at = start + int(b["offset"])
             m = _batch_message(buf, at)
             if m["compressed"]:
@@ -644,7 +645,7 @@ def _arrow_tail(pa, schema, blocks: np.ndarray) -> bytes:
 
 
 def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: bool = False, file_identifier=None,
-               section_marker: bytes = None, consume: bool = False) -> int:
+               section_marker: bytes = None, consume: bool = False, _live: dict = None) -> int:
     """POD5 shards written by this package (the out.rankN.pod5 files of a multi-process run) -> one file with the reads in the order
     given.  The signal table is re-batched WITHOUT touching a sample: every output batch of SIGNAL_BATCH_ROWS rows is a patched
     copy of pyarrow's own message metadata, the 16-byte ids / offsets / sample counts of its rows (3 KB, from the shards' memory
@@ -653,7 +654,11 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
     columnar, no per-read object), the run-info table and the two footers are built anew.  The result is byte for byte what
     Pod5FileWriter writes when it is handed all the reads in turn.  take_first: the first shard BECOMES the output (its full signal
     batches stay where they are); consume: every other shard is deleted once its rows are in.  -> number of reads;
-    merge_pod5.last holds bytes / seconds."""
+    merge_pod5.last holds bytes / seconds.
+    _live (merge.LiveJoin): the output is open already (`fd`) and holds shard 0's head and the full batches the live join copied
+    while the ranks ran -- `blocks` (their Arrow blocks), `placed[r]` (the output batch of each of shard r's copied batches) --
+    so only every shard's rows behind its copied batches are laid out here, behind those batches, and the tables are built with
+    the row indices that follow from both."""
     import os
     import time
     from . import merge as M
@@ -668,7 +673,7 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
         for p_, sc in zip(paths[1:], sig_schemas[1:]):
             if sc.remove_metadata() != sig_schemas[0].remove_metadata():
                 raise ValueError(f"{p_}: signal table schema differs from {paths[0]} (VBZ and uncompressed shards do not mix)")
-        if take_first:
+        if take_first or _live is not None:                # (the live join started the output with shard 0's head)
             file_identifier, section_marker = shards[0].footer["file_identifier"], bytes(shards[0].marker)
         file_identifier = file_identifier or uuid.uuid4()
         marker = section_marker or uuid.uuid4().bytes
@@ -677,13 +682,31 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
         width = 1 if vbz else 2
 
         # ---- every signal row of every shard, in output order
-        per = [s_.signal_rows(vbz) for s_ in shards]
+        R = SIGNAL_BATCH_ROWS
+        live_blocks = np.zeros(0, _BLOCK)
+        placed = [np.zeros(0, np.int64)] * len(shards)
+        if _live is not None:
+            placed = [np.asarray(x, dtype=np.int64) for x in _live["placed"]]
+            live_blocks = np.asarray(_live["blocks"], dtype=_BLOCK)
+        per = [s_.signal_rows(vbz, skip_batches=len(k_)) for s_, k_ in zip(shards, placed)]
         n_rows = [len(p_[1]) for p_ in per]
+        rows_in_shard = [R * len(k_) + n_ for k_, n_ in zip(placed, n_rows)]
+        # where every signal row of shard r ends up in the output: behind the rows of the earlier shards -- or, live, in the batch
+        # its own batch was copied to, and for the rows behind those batches: behind all copied batches, shard after shard
+        row_maps, base = [], R * len(live_blocks)
+        for r in range(len(shards)):
+            tail_map = np.arange(n_rows[r], dtype=np.int64) + base
+            base += n_rows[r]
+            if _live is None:
+                row_maps.append(tail_map)
+            else:
+                local = np.arange(R * len(placed[r]), dtype=np.int64)
+                row_maps.append(np.concatenate([R * placed[r][local // R] + local % R, tail_map]))
+            assert len(row_maps[-1]) == rows_in_shard[r]
         ids, counts = np.concatenate([p_[0] for p_ in per]), np.concatenate([p_[1] for p_ in per])
         lens, pos = np.concatenate([p_[2] for p_ in per]), np.concatenate([p_[3] for p_ in per])
         shard_of = np.repeat(np.arange(len(shards)), n_rows)
         n = len(counts)
-        R = SIGNAL_BATCH_ROWS
         n_batches = -(-n // R)
         first_row = np.arange(n_batches, dtype=np.int64) * R
         cum = np.concatenate([[0], np.cumsum(lens)])                       # in bytes (VBZ) or samples
@@ -706,11 +729,14 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
             body_len[b] = len(msg) - m["meta"] + grow
             data_at[b] = m["meta"] + bufs[di, 0]
             msg_at[b + 1] = m["meta"] + body_len[b]
-        msg_at = len(head) + np.concatenate([[0], np.cumsum(msg_at[1:])])
+        msg_base = len(head) if _live is None else int(_live["msg_base"])          # (live: behind the batches copied while the ranks ran)
+        if _live is not None and _live["head_len"] != len(head):
+            raise ValueError("the shards' signal tables do not start as this writer starts them")
+        msg_at = msg_base + np.concatenate([[0], np.cumsum(msg_at[1:])])
         blocks = np.zeros(n_batches, _BLOCK)
         blocks["offset"], blocks["body"] = msg_at[:-1], body_len
         blocks["meta"] = [tmpl[R if b < n_batches - 1 or k_last == R else k_last][1]["meta"] for b in range(n_batches)]
-        tail = _arrow_tail(pa, schema, blocks)
+        tail = _arrow_tail(pa, schema, np.concatenate([live_blocks, blocks]))
 
         # ---- the data runs: rows that follow each other in a shard batch AND in an output batch move as one range
         batch_of = np.arange(n, dtype=np.int64) // R
@@ -736,7 +762,7 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
                     if take_first and shard_of[i] == 0]
         stash = [(d, bytes(shards[0].buf[p_:p_ + nb])) for _, p_, d, nb in in_place]   # the one partial batch of shard 0: <= R rows
         # (the tables behind shard 0's signal table are read before take_first lets the copies run over them)
-        cols, run_ids, run_infos, pore_types = _merged_read_columns(pa, shards, n_rows)
+        cols, run_ids, run_infos, pore_types = _merged_read_columns(pa, shards, row_maps)
         del per
 
         # ---- the small parts of every batch that moves -- message metadata + ids + offsets in front of the data, sample counts behind
@@ -777,7 +803,9 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
 
         remover = M._Remover(consume)
         with M._Files() as files:
-            if take_first:
+            if _live is not None:
+                fd = _live["fd"]                                         # (the live join's descriptor; it closes it)
+            elif take_first:
                 os.replace(paths[0], out)
                 fd = files.open(out, os.O_RDWR)
             else:
@@ -823,8 +851,8 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
                 f.truncate()
                 _write_tail(f, pa, meta, marker, file_identifier, sig_start, run_infos, cols, run_ids, pore_types)
         removing = remover.finish()
-        merge_pod5.last = {"bytes_copied": int(copied), "seconds": time.perf_counter() - t0, "signal_rows": int(n),
-                           "batches_in_place": int(keep), "remove_seconds": removing, "threads": threads,
+        merge_pod5.last = {"bytes_copied": int(copied), "seconds": time.perf_counter() - t0, "signal_rows": int(n) + R * len(live_blocks),
+                           "batches_in_place": int(keep), "batches_copied_live": len(live_blocks), "remove_seconds": removing, "threads": threads,
                            "engine": "map" if M.merge_engine() else "fd"}
         return len(cols["read_number"])
     finally:
@@ -838,15 +866,15 @@ def merge_pod5(paths: Sequence[str], out: str, threads: int = None, take_first: 
 merge_pod5.last = {}
 
 
-def _merged_read_columns(pa, shards, n_rows):
-    """The reads tables of the shards as ONE set of columns (for _reads_table): signal-row indices shifted by the rows of the
-    earlier shards, pore-type and run-info dictionaries united (run infos in order of first appearance, by acquisition id)."""
+def _merged_read_columns(pa, shards, row_maps):
+    """The reads tables of the shards as ONE set of columns (for _reads_table): signal-row indices translated by row_maps[r] (where
+    signal row i of shard r sits in the output), pore-type and run-info dictionaries united (run infos in order of first
+    appearance, by acquisition id)."""
     names = [n for n, _ in READ_COLUMNS]
     parts = {k: [] for k in names + ["read_id", "signal_rows", "pore_type", "end_reason", "run_info"]}
     list_lens = []
     run_ids, run_infos, pore_seen, pending = [], [], set(), []
-    base = 0
-    for s_, rows in zip(shards, n_rows):
+    for s_, row_map in zip(shards, row_maps):
         t = s_.table(CT_READS).read_all()
         runs = {ri["acquisition_id"]: ri for ri in s_.table(CT_RUN_INFO).read_all().to_pylist()}
         for name, dt in READ_COLUMNS:
@@ -858,9 +886,8 @@ def _merged_read_columns(pa, shards, n_rows):
         sig = t.column("signal").combine_chunks()
         offs = sig.offsets.to_numpy()
         list_lens.append(np.diff(offs))
-        parts["signal_rows"].append(sig.values.to_numpy()[offs[0]:offs[-1]].astype(np.uint64) + np.uint64(base)
+        parts["signal_rows"].append(np.asarray(row_map, dtype=np.uint64)[sig.values.to_numpy()[offs[0]:offs[-1]].astype(np.int64)]
                                     if len(sig) else np.zeros(0, np.uint64))
-        base += rows
         for key in ("pore_type", "end_reason", "run_info"):
             c = t.column(key).combine_chunks()
             idx = c.indices.to_numpy().astype(np.int64) if len(c) else np.zeros(0, np.int64)

@@ -432,3 +432,37 @@ def test_a_run_far_above_the_redo_threshold_on_the_fast_path_says_so(tmp_path, c
     assert equal >= 3
     with pytest.raises(ValueError, match="attention_path"):
         run(sharp, tmp_path / "x.blow5", "sideways")
+
+
+@pytest.mark.parametrize("ext", ["blow5", "pod5"])
+def test_live_join_of_a_three_rank_run_holds_the_single_process_reads(tmp_path, ext):
+    """`predict --gpus 3 --join live` (all ranks on this box's one GPU): the parent joins the rank files WHILE the ranks write them
+    (merge.LiveJoin); the one file that comes out holds exactly the reads of the single-process run -- ids, read numbers, offset
+    draws, int16 samples -- in the round-robin order of the live join (BLOW5) / with the reads table in read order (POD5), no rank
+    file is left, and a third rank without reads (more ranks than reads in the second case) is no obstacle."""
+    from seq2squiggle_amd import pod5_io
+    lam = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for n_reads, tag in ((900, "many"), (2, "few")):
+        base = [sys.executable, "-m", "seq2squiggle_amd", "predict", lam, "-n", str(n_reads), "-r", "3000", "-m",
+                os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--seed", "21"]
+        one, live = str(tmp_path / f"{tag}_one.{ext}"), str(tmp_path / f"{tag}_live.{ext}")
+        r = subprocess.run(base + ["-o", one], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env0)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run(base + ["-o", live, "--gpus", "3", "--join", "live"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                           env=dict(env0, S2S_ONE_GPU="1"))
+        assert r.returncode == 0 and f"{n_reads} reads from 3 ranks" in r.stdout and "joined meanwhile" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+        assert sorted(f for f in os.listdir(tmp_path) if f.startswith(f"{tag}_live")) == [f"{tag}_live.{ext}"]
+        if ext == "blow5":
+            a = {x["read_id"]: x for x in signal_io.read_blow5(one)[1]}
+            got = signal_io.read_blow5(live)[1]
+            assert len(got) == len(a) == n_reads and {x["read_id"] for x in got} == set(a)
+            for x in got:
+                y = a[x["read_id"]]
+                assert np.array_equal(x["signal"], y["signal"]) and x["read_number"] == y["read_number"] and x["offset"] == y["offset"]
+        else:
+            a, got = pod5_io.read_pod5(one)["reads"], pod5_io.read_pod5(live)["reads"]
+            assert len(got) == len(a) == n_reads
+            for x, y in zip(got, a):                                     # the reads table keeps the read order
+                assert x["read_id"] == y["read_id"] and x["read_number"] == y["read_number"] and np.array_equal(x["signal"], y["signal"])
+                assert x["calibration_offset"] == y["calibration_offset"]

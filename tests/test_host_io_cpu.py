@@ -833,3 +833,125 @@ def test_cpu_share_honours_quota_and_ranks(monkeypatch):
     monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     assert signal_io.cpu_share() == max(1, min(16, cores) // 8)
+
+
+def _live_join_case(tmp_path, ext, lens, splits, delays, tag, batch=40, signal_compression=None):
+    """Rank writers on threads (each appending its shard in batches with its own pauses) beside a LiveJoin that steps in a loop, as
+    cli._launch_ranks does; -> (output path, shard paths kept as copies for the reference join)."""
+    import shutil
+    import threading
+    import time
+    from seq2squiggle_amd import merge as M, pod5_io
+    prof = U.get_profile("dna-r10-prom")
+    rng = np.random.default_rng(17)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = (600 + 40 * rng.standard_normal(offs[-1])).astype(np.int16)
+    ids = [f"read{i}" for i in range(len(lens))]
+    shards = [parallel.rank_output_path(str(tmp_path / f"{tag}.{ext}"), r, len(splits)) for r in range(len(splits))]
+    done = [False] * len(splits)
+    # every rank's writer and records first, one rank after the other (np.random's global stream: a rank PROCESS seeds it and draws
+    # alone); the threads below only write them out, each at its own pace
+    writers, batches = [], []
+    for r, (lo, hi) in enumerate(splits):
+        np.random.seed(8)
+        if ext == "pod5":
+            w = signal_io.POD5Writer(shards[r], prof, False, "dna-r10-prom", False)
+        else:
+            w = signal_io.BLOW5Writer(shards[r], prof, False, "dna-r10-prom", False)
+        if lo:
+            w.start_at(lo)
+        writers.append(w)
+        batches.append([w.dac_records(ids[a:min(a + batch, hi)], flat[offs[a]:offs[min(a + batch, hi)]], offs[a:min(a + batch, hi) + 1] - offs[a])
+                        for a in range(lo, hi, batch)] or [[]])
+
+    def rank(r):
+        w = writers[r]
+        time.sleep(delays[r][0])
+        if ext == "pod5":
+            w._stream = pod5_io.Pod5FileWriter(shards[r], signal_compression=signal_compression)
+        for recs in batches[r]:
+            w.write_records(recs)
+            time.sleep(delays[r][1])
+        if hasattr(w, "close"):
+            w.close()
+        done[r] = True
+    out = str(tmp_path / f"{tag}.live.{ext}")
+    live = M.LiveJoin(shards, out, threads=2, punch=True)
+    live.q = 7 if ext == "blow5" else 2           # small quanta: many turns on a small case
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(len(splits))]
+    for t in ts:
+        t.start()
+    while not all(done):
+        if not live.step(list(done)):
+            time.sleep(0.002)
+    for t in ts:
+        t.join()
+    keep = [shutil.copy(p_, p_ + f".keep.{ext}") for p_ in shards]     # (punched where the live join has been: NOT valid inputs any more)
+    n, st = live.finish(consume=True)
+    assert not any(os.path.exists(p_) for p_ in shards)
+    return out, n, st
+
+
+@pytest.mark.parametrize("ext", ["blow5", "pod5", "pod5-none"])
+def test_live_join_holds_the_same_reads_in_a_timing_independent_order(tmp_path, ext):
+    """--join live (merge.LiveJoin): the parent copies complete records / full signal batches out of rank files that are still being
+    written.  The result must be a valid container with exactly the reads of a single-process run -- ids, numbers, draws, samples --
+    and its layout must depend on the ranks' record sequences only, not on who was faster: two runs with opposite pauses give the
+    same BLOW5 bytes / the same POD5 row placement."""
+    from seq2squiggle_amd import pod5_io
+    comp = "none" if ext.endswith("-none") else None
+    ext = ext.split("-")[0]
+    rng = np.random.default_rng(23)
+    lens = [int(x) for x in rng.integers(200, 5000, 523)] + [102400, 250000, 7]
+    lens = lens if ext == "pod5" else lens[:523]
+    n_reads = len(lens)
+    splits = ((0, 170), (170, 170), (170, 400), (400, n_reads))                 # rank 1 has no reads
+    prof = U.get_profile("dna-r10-prom")
+    # the single-process file
+    rng2 = np.random.default_rng(17)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = (600 + 40 * rng2.standard_normal(offs[-1])).astype(np.int16)
+    ids = [f"read{i}" for i in range(n_reads)]
+    np.random.seed(8)
+    if ext == "pod5":
+        w = signal_io.POD5Writer(str(tmp_path / "one.pod5"), prof, False, "dna-r10-prom", False)
+        w._stream = pod5_io.Pod5FileWriter(str(tmp_path / "one.pod5"), signal_compression=comp)
+        w.write_records(w.dac_records(ids, flat, offs))
+        w.close()
+        one = {str(r["read_id"]): r for r in pod5_io.read_pod5(str(tmp_path / "one.pod5"))["reads"]}
+    else:
+        w = signal_io.BLOW5Writer(str(tmp_path / "one.blow5"), prof, False, "dna-r10-prom", False)
+        w.save_dac(ids, flat, offs)
+        one = {r["read_id"]: r for r in signal_io.read_blow5(str(tmp_path / "one.blow5"))[1]}
+    outs = []
+    for k, delays in enumerate((((0.0, 0.004), (0.01, 0.0), (0.02, 0.001), (0.0, 0.0)),
+                                ((0.03, 0.0), (0.0, 0.0), (0.0, 0.003), (0.01, 0.005)))):
+        out, n, st = _live_join_case(tmp_path, ext, lens, splits, delays, f"run{k}", signal_compression=comp)
+        assert n == n_reads and st["units_live"] > 0 and 0 < st["live_bytes"] < st["bytes"], st      # payload went while the "ranks" wrote
+        outs.append(out)
+        if ext == "pod5":
+            got = pod5_io.read_pod5(out)
+            assert [r["read_number"] for r in got["reads"]] == list(range(n_reads))     # the reads table stays in read order
+            assert len(got["run_info"]) == 1 and got["signal_rows"] == sum(-(-x // pod5_io.SIGNAL_CHUNK) for x in lens)
+            for r in got["reads"]:
+                ref = one[str(r["read_id"])]
+                assert np.array_equal(r["signal"], ref["signal"]) and r["read_number"] == ref["read_number"]
+                assert r["calibration_offset"] == ref["calibration_offset"] and r["median_before"] == ref["median_before"]
+            assert sum(1 for _ in pod5_io.iter_pod5(out)) == n_reads                    # (the batch-at-a-time reader agrees with the layout)
+        else:
+            _, got = signal_io.read_blow5(out)
+            assert len(got) == n_reads and {r["read_id"] for r in got} == set(one)
+            for r in got:
+                ref = one[r["read_id"]]
+                assert np.array_equal(r["signal"], ref["signal"]) and r["read_number"] == ref["read_number"] and r["offset"] == ref["offset"]
+            assert [r["read_number"] for r in got] != list(range(n_reads))              # an interleave, by design
+    if ext == "blow5":
+        assert open(outs[0], "rb").read() == open(outs[1], "rb").read()
+    else:
+        place = []
+        for o in outs:
+            t = pod5_io._Shard(o)
+            tab = t.table(pod5_io.CT_READS).read_all()
+            place.append(tab.column("signal").to_pylist())
+            t.close()
+        assert place[0] == place[1]

@@ -32,4 +32,14 @@ print(f"predict --gpus {sys.argv[3]} (one GPU) -> merged .pod5: {len(a)} reads, 
 sys.exit(0 if same else 1)
 PY
 grep -E "real|reads from" $out/predict_${N}ranks_one_gpu.log | tail -5 | tee -a $out/README.txt
+( time S2S_ONE_GPU=1 timeout -k 10 900 python -m seq2squiggle_amd predict $common -o $tmp/live.pod5 --gpus $N --join live ) > $out/predict_${N}ranks_one_gpu_join_live.log 2>&1 || { echo "predict --gpus $N --join live failed"; tail -20 $out/predict_${N}ranks_one_gpu_join_live.log; exit 1; }
+python - $tmp/live.pod5 $tmp/single.pod5 <<'PY' | tee -a $out/README.txt
+import sys, numpy as np
+from seq2squiggle_amd import pod5_io
+a, b = pod5_io.read_pod5(sys.argv[1])["reads"], pod5_io.read_pod5(sys.argv[2])["reads"]
+same = len(a) == len(b) and all(np.array_equal(x["signal"], y["signal"]) and x["read_number"] == y["read_number"] and x["read_id"] == y["read_id"] for x, y in zip(a, b))
+print(f"--join live: {len(a)} reads; per-read ids, samples and numbering equal to the single-process file: {same}")
+sys.exit(0 if same else 1)
+PY
+grep -E "real|reads from" $out/predict_${N}ranks_one_gpu_join_live.log | tail -3 | sed 's/^/join live: /' | tee -a $out/README.txt
 grep -E "real" $out/predict_single.log | tail -2 | sed 's/^/single process: /' | tee -a $out/README.txt
