@@ -124,7 +124,12 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
                 if os.path.exists(stale):
                     os.remove(stale)
             live = LiveJoin(shard_paths, partial)
-        rc, timing, reap = _launch_ranks(gpus, live)
+        try:
+            rc, timing, reap = _launch_ranks(gpus, live)
+        except BaseException:
+            if live is not None:
+                live.abort()                    # (a rank file the live join could not make sense of: no partial output stays behind)
+            raise
         timing["ranks_seconds"] = time.time() - t0
         if live is not None:
             if rc == 0:
