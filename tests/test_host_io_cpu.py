@@ -955,3 +955,20 @@ def test_live_join_holds_the_same_reads_in_a_timing_independent_order(tmp_path, 
             place.append(tab.column("signal").to_pylist())
             t.close()
         assert place[0] == place[1]
+
+
+def test_live_join_refuses_a_rank_file_that_does_not_end(tmp_path):
+    """A rank that is 'done' but whose file stops in the middle of a record (a crash after the stamp cannot happen, a full disk
+    can): the live join raises instead of closing a container with a torn record, and abort() leaves no output behind."""
+    from seq2squiggle_amd import merge as M
+    rng = np.random.default_rng(2)
+    shards = _write_shards(tmp_path, "blow5", list(rng.integers(100, 900, 30)), ((0, 12), (12, 30)), rng, tag="t")
+    whole = open(shards[1], "rb").read()
+    open(shards[1], "wb").write(whole[:-9])                      # the end marker and four bytes of the last record are missing
+    live = M.LiveJoin(shards, str(tmp_path / "t.live.blow5"), threads=1, punch=False)
+    with pytest.raises(ValueError, match="end-of-file marker"):
+        live.finish()
+    live.abort()
+    assert not os.path.exists(tmp_path / "t.live.blow5") and all(os.path.exists(p_) for p_ in shards)
+    with pytest.raises(ValueError, match=".blow5 and .pod5"):
+        M.LiveJoin(shards, str(tmp_path / "x.slow5"))
