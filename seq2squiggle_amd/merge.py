@@ -350,7 +350,7 @@ class LiveJoin:
         if self.exhausted[r]:
             return True
         if not self._open(r):
-            if done:                                # a rank that ended without a file (it always writes one, even empty): let finish() say so
+            if done:                                # (a rank always leaves a file, even without reads: inference_run sees to it)
                 raise FileNotFoundError(f"{self.paths[r]}: the rank is done but its file is missing or has no header")
             return False
         fd = self.fds[r]
