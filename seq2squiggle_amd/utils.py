@@ -20,7 +20,6 @@ from typing import Dict, Generator, Iterable, List, Tuple
 from uuid import uuid4
 
 import numpy as np
-import scipy.stats as st
 
 logger = logging.getLogger("seq2squiggle")
 
@@ -157,10 +156,11 @@ def read_fasta(path: str, rna: bool = False) -> Generator[Tuple[str, str], None,
 # --------------------------------------------------------------------------------------- read sampling
 # Read-length laws (reference utils.py:311-331): a scipy distribution fitted to real runs, rescaled so that its mean is the
 # requested -r.  name -> (distribution, shape/loc/scale arguments, mean of the fitted law)
+# (scipy.stats is imported when a length is drawn through it -- 0.3 - 0.6 s that a rank whose sampler is replayed natively never pays)
 _LENGTH_LAWS = {
-    "expon": (st.expon, dict(loc=213.98910256668592, scale=6972.5319847131141), 7106.0),
-    "beta": (st.beta, dict(a=1.778, b=7.892, loc=316.758, scale=34191.257), 6615.0),
-    "gamma": (st.gamma, dict(a=6.3693711, loc=0.53834893), 4.39),
+    "expon": ("expon", dict(loc=213.98910256668592, scale=6972.5319847131141), 7106.0),
+    "beta": ("beta", dict(a=1.778, b=7.892, loc=316.758, scale=34191.257), 6615.0),
+    "gamma": ("gamma", dict(a=6.3693711, loc=0.53834893), 4.39),
 }
 
 
@@ -170,8 +170,9 @@ _NATIVE_LAWS = {"expon": 0, "gamma": 1, "beta": 2}     # s2s_sampler_replay_law'
 def draw_length(distr: str, mean, seed, total_len):
     """One read length: a single variate from a generator seeded with `seed` (scipy builds a fresh legacy RandomState per
     call), truncated to an integer and clipped to [1, total_len]."""
+    import scipy.stats as st
     law, args, fitted_mean = _LENGTH_LAWS[distr]
-    x = law.rvs(size=1, random_state=seed, **args)[0]
+    x = getattr(st, law).rvs(size=1, random_state=seed, **args)[0]
     return np.clip(int(x * mean / fitted_mean), 1, total_len)
 
 
