@@ -111,25 +111,30 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
             raise FileExistsError(f"{out} exists (the POD5 writer refuses to overwrite, like pod5.Writer)")
         import time
         t0 = time.time()
-        live = None
+        live, make_live = None, None
         if join_mode == "live" and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
             if not str(out).endswith((".blow5", ".pod5")):
                 raise click.UsageError("--join live handles .blow5 and .pod5 outputs")
-            from .merge import LiveJoin
-            from .parallel import rank_output_path
             ext = os.path.splitext(str(out))[1]
-            partial = str(out)[:len(str(out)) - len(ext)] + ".partial" + ext
-            shard_paths = [rank_output_path(str(out), r, gpus) for r in range(gpus)]
+            base_name = str(out)[:len(str(out)) - len(ext)]
+            partial = base_name + ".partial" + ext
+            shard_paths = [f"{base_name}.rank{r}{ext}" for r in range(gpus)]       # (parallel.rank_output_path, without its imports)
             for stale in [partial] + shard_paths:           # (a rank file left by an earlier run must not be mistaken for this run's)
                 if os.path.exists(stale):
                     os.remove(stale)
-            live = LiveJoin(shard_paths, partial)
+            holder = {}
+
+            def make_live():                                # (called once the ranks are started: numpy loads beside their start-up, not before it)
+                from .merge import LiveJoin
+                holder["live"] = LiveJoin(shard_paths, partial)
+                return holder["live"]
         try:
-            rc, timing, reap = _launch_ranks(gpus, live)
+            rc, timing, reap = _launch_ranks(gpus, make_live)
         except BaseException:
-            if live is not None:
-                live.abort()                    # (a rank file the live join could not make sense of: no partial output stays behind)
+            if make_live is not None and holder.get("live") is not None:
+                holder["live"].abort()          # (a rank file the live join could not make sense of: no partial output stays behind)
             raise
+        live = holder.get("live") if make_live is not None else None
         timing["ranks_seconds"] = time.time() - t0
         if live is not None:
             if rc == 0:
@@ -223,7 +228,7 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
         os._exit(0)
 
 
-def _launch_ranks(gpus: int, live=None):
+def _launch_ranks(gpus: int, make_live=None):
     """`predict --gpus N` outside torchrun: the same command line once per GPU, as N CHILD processes of this one (which never touches
     the GPU) with the environment torchrun would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1,
     MASTER_PORT) -- started directly: the elastic agent of torch.distributed.run costs an import of torch in the parent and a
@@ -231,7 +236,8 @@ def _launch_ranks(gpus: int, live=None):
     others (by their pids).  S2S_DRY_LAUNCH=1 prints the child command and environment instead of running it.
     -> (exit code, {"launch_seconds": spawn -> the slowest rank is ready to read its input, "predict_seconds": ... -> the slowest is
     done}, reap): returns as soon as every rank's output file is complete and closed; reap() collects the processes afterwards.
-    live (merge.LiveJoin): its step() runs in the waiting loop, so that the rank files are joined while they grow."""
+    make_live() -> merge.LiveJoin, called once the ranks are started: its step() runs in the waiting loop, so that the rank files are
+    joined while they grow."""
     import json
     import os
     import shutil
@@ -285,7 +291,10 @@ def _launch_ranks(gpus: int, live=None):
                 code = code or 1
         shutil.rmtree(timing_dir, ignore_errors=True)
         return code
+    live = None
     try:
+        if make_live is not None:
+            live = make_live()
         try:                                    # the merge's imports (numpy, pyarrow, the library) load while the ranks work
             from . import merge, pod5_io, signal_io  # noqa: F401
             pod5_io._pa()

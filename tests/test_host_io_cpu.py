@@ -972,3 +972,12 @@ def test_live_join_refuses_a_rank_file_that_does_not_end(tmp_path):
     assert not os.path.exists(tmp_path / "t.live.blow5") and all(os.path.exists(p_) for p_ in shards)
     with pytest.raises(ValueError, match=".blow5 and .pod5"):
         M.LiveJoin(shards, str(tmp_path / "x.slow5"))
+
+
+def test_cli_rank_file_names_are_those_of_the_ranks():
+    """`predict --gpus N --join live` names the rank files itself before it starts the ranks (so that nothing heavy is imported in front
+    of their start): the names must be parallel.rank_output_path's, which the ranks use."""
+    for out in ("a/b/out.blow5", "x.pod5", "dir.v2/reads.final.blow5"):
+        ext = os.path.splitext(out)[1]
+        base = out[:len(out) - len(ext)]
+        assert [f"{base}.rank{r}{ext}" for r in range(3)] == [parallel.rank_output_path(out, r, 3) for r in range(3)]
