@@ -448,8 +448,14 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
                 uv4 q2 = __builtin_bit_cast(uv4, qb2);
                 q2[0] = h ? pk : q2[0];
                 qb2m = __builtin_bit_cast(h8, q2);
+#if S2S_FAST_HI_MAX
+                // (what the maxima were taken from IS the first product of the score: the second MFMA accumulates onto it)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, sc[i]);
+#else
 #pragma unroll
                 for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, MFMAW(ka[i], qb1, zero16));
+#endif
             }
 #else
             f32x16 sc[2];
@@ -618,7 +624,13 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
             for (int r = 0; r < 9; ++r) O[r] *= f;
         }
         m = m_enc;
+#if S2S_ONLINE_HI_MAX
+        // the full score = what the maxima were taken from + the second MFMA (K_hi . Q_lo and the shift); the phantom keys stay -inf
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sc[i] = MFMAW(kb[i], qb2m, sc[i]);
+#else
         score_pass();
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
