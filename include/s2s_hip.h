@@ -305,8 +305,8 @@ int64_t s2s_blow5_scan_upto(int32_t fd, int64_t begin, int64_t limit, int64_t ma
  *      attention (the committed synthetic checkpoints redo nothing; their decoder w_qs / w_ks x 2: 6.4 % of the heads);
  *   1  the EXACT path at once: the online softmax (running row maximum raised and sums rescaled in every 64-key pass, no branch;
  *      the shift rides in the score MFMA's k-slots, a pass's row maxima come from its first score MFMA alone, natural key
- *      order) as the only path of its own kernel instance: 203.8 k shader cycles per chunk and CU against the fast path's 190.2 k
- *      on diffuse attention (7.2 % more), the same for ANY weights -- "fast, then redo" costs 310-328 k once most heads overflow
+ *      order) as the only path of its own kernel instance: 201.6 k shader cycles per chunk and CU against the fast path's 190.2 k
+ *      on diffuse attention (6.0 % more), the same for ANY weights -- "fast, then redo" costs 310-328 k once most heads overflow
  *      (sharply peaked attention).
  * s2s_create chooses by a calibration launch on a fixed pseudo-random batch: exact when more than S2S_ATTENTION_REDO_THRESHOLD of
  * its heads had to be redone (where the two cost the same).  The environment variable S2S_ATTENTION_PATH = fast | exact (any

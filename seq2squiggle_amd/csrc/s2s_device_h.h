@@ -540,12 +540,13 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
 // The EXACT attention path (s2s_fused_kernel<.., EXACT = true>, s2s_set_attention_path; s2s_create picks it for weights whose
 // calibration launch redoes more than S2S_ATTENTION_REDO_THRESHOLD of its heads) is the online softmax -- running maximum raised
 // and sums rescaled in every 64-key pass, branch-free -- as the ONLY path of its kernel instance: the same shader cycles per chunk
-// on every checkpoint, whatever the weights (203.8 k, profiles/r05/attention_paths.txt), where "fast path, then redo" costs 190.2 k on
+// on every checkpoint, whatever the weights (201.6 k, profiles/r05/attention_paths.txt), where "fast path, then redo" costs 190.2 k on
 // diffuse attention and 310-328 k once most
 // heads overflow.  As softmax_pv32<TV, SAFE = true> (the fast instance's out-of-line fallback) it measured 221.7 k; as
 // softmax_pv32_online below 209.0 k with every pass's maxima taken from the full score (206.5 k on round 4's device, 211.8 k while
 // the exact instance still shared the fast one's dealt-out key order: the phantom-key masks sat in two passes and the kernel
-// spilled 7 registers), 203.8 k with the maxima from the first score MFMA alone (S2S_ONLINE_HI_MAX, round 5).
+// spilled 7 registers), 203.8 k with the maxima from the first score MFMA alone (S2S_ONLINE_HI_MAX, round 5), 201.6 k with the score's second MFMA
+// accumulating onto that product instead of both being issued again (bit-identical; the masks applied once).
 // (Round 5 also tried it in two phases -- the row maxima of all eight tiles from that first MFMA, then the fast path's body with the
 // exact shift, no update or rescale in the loop, commit 7131d25: unrolled, hipcc hoists phase 1 to the front and spills 52 registers; as
 // a real loop it runs 218.8 k: the separate phase exposes the K reads and the MFMA chain that the online loop hides.)

@@ -1153,8 +1153,9 @@ static int calibrate_attention(s2s_handle* h) {
     if (rs != S2S_OK) return rs;
     h->calib_redo_rate = st[1] ? (double)st[2] / (double)st[1] : 0.0;
     // (measured: a redone head also holds its seven partner waves at the next barrier, so a redo share r costs ~ 235 k x r cycles per
-    //  chunk while r is small -- 6.4 %: + 14.7 k -- and 153 k x r once most heads redo; the exact instance costs + 13.6 k whatever the
-    //  weights (203.8 k against 190.2 k, profiles/r05/attention_paths.txt): they break even at r = 5.5 - 6 %)
+    //  chunk while r is small -- 6.4 %: + 14.7 k -- and 153 k x r once most heads redo; the exact instance costs + 11.4 k whatever the
+    //  weights (201.6 k against 190.2 k, profiles/r05/attention_paths.txt): they break even at r = 5 - 5.5 % in cycles; in
+    //  chunks per second -- the clock follows the operands -- the two are level at 6.4 %)
     h->attn_exact = h->calib_redo_rate > S2S_ATTENTION_REDO_THRESHOLD ? 1 : 0;
     return S2S_OK;
 }
