@@ -62,9 +62,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ONLINE2
 #define S2S_ONLINE2 1           // the exact instance runs softmax_pv32_online (0: the fast instance's out-of-line fallback, A/B)
 #endif
-#ifndef S2S_REDO_ONLINE
-#define S2S_REDO_ONLINE 0       // the fast instance redoes an overflowed head with softmax_pv32_online instead of the textbook fallback (A/B)
-#endif
 #ifndef S2S_FAST_HI_MAX
 #define S2S_FAST_HI_MAX 1       // the fast path's pass 0 takes its row maxima from the first score MFMA alone (0: from the full score; + 1.05 %, same MAE)
 #endif
@@ -855,11 +852,10 @@ __device__ __forceinline__ void fft_block_h(const float* __restrict__ W, const L
 #endif
                         if (__builtin_expect(redo, 0)) {
                             if (lane == 0) atomicAdd(&s2s_stats_lds[S2S_STAT_REDO], 1u);     // production counter (s2s_stats_read)
-#if S2S_REDO_ONLINE && S2S_ONLINE2 && S2S_ATT32_MSLOT
-                            softmax_pv32_online<TV, LO, false>(kp, kp2, vp, qb1, qb2, one, hl, O);      // (the fast instance's key order)
-#else
+                            // (the textbook fallback, not softmax_pv32_online: as the out-of-line branch of THIS kernel the faster function
+                            //  costs the fast path 2.2 k cycles of registers and schedule -- commit 066dc5f -- and the weights that redo much run
+                            //  the exact instance anyway)
                             softmax_pv32<TV, true, LO>(kp, kp2, vp, qb1, qb2, one, hl, O);
-#endif
                             lsum = sum_h(O[8]);
                         }
                     }
