@@ -981,3 +981,28 @@ def test_cli_rank_file_names_are_those_of_the_ranks():
         ext = os.path.splitext(out)[1]
         base = out[:len(out) - len(ext)]
         assert [f"{base}.rank{r}{ext}" for r in range(3)] == [parallel.rank_output_path(out, r, 3) for r in range(3)]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_live_join_random_shapes_and_paces(tmp_path, seed):
+    """LiveJoin over random rank counts, splits (empty ranks included), read lengths and writer paces, BLOW5 and POD5 by turns: the
+    output always parses, holds every read once with the single-stream ids and samples, and leaves no rank file behind."""
+    from seq2squiggle_amd import pod5_io
+    rng = np.random.default_rng(100 + seed)
+    ext = ("blow5", "pod5", "pod5")[seed % 3]
+    n_ranks = int(rng.integers(2, 6))
+    n_reads = int(rng.integers(150, 700))
+    lens = [int(x) for x in rng.integers(50, 3000, n_reads)]
+    cuts = sorted(int(x) for x in rng.integers(0, n_reads + 1, n_ranks - 1))
+    bounds = [0] + cuts + [n_reads]
+    splits = tuple((bounds[i], bounds[i + 1]) for i in range(n_ranks))
+    delays = tuple((float(rng.uniform(0, 0.02)), float(rng.uniform(0, 0.004))) for _ in range(n_ranks))
+    out, n, st = _live_join_case(tmp_path, ext, lens, splits, delays, f"rnd{seed}", batch=int(rng.integers(5, 90)))
+    assert n == n_reads and not [f for f in os.listdir(tmp_path) if ".rank" in f and ".keep." not in f]
+    if ext == "pod5":
+        got = pod5_io.read_pod5(out)["reads"]
+        assert [r["read_number"] for r in got] == list(range(n_reads)) and [len(r["signal"]) for r in got] == lens
+    else:
+        got = signal_io.read_blow5(out)[1]
+        assert sorted(r["read_number"] for r in got) == list(range(n_reads))
+        assert {r["read_number"]: r["len_raw_signal"] for r in got} == dict(enumerate(lens))
