@@ -17,7 +17,7 @@ import datetime as _dt
 import io
 import struct
 import uuid
-from typing import Dict, List, Sequence
+from typing import List, Sequence
 
 import numpy as np
 
