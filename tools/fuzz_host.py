@@ -281,6 +281,8 @@ L.s2s_copy_ranges.restype = i64
 L.s2s_copy_ranges.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32]
 L.s2s_blow5_scan.restype = i64
 L.s2s_blow5_scan.argtypes = [i32, i64, i64]
+L.s2s_blow5_scan_upto.restype = i64
+L.s2s_blow5_scan_upto.argtypes = [i32, i64, i64, i64, vp]
 
 
 def check_merge_helpers(threads):
@@ -327,6 +329,19 @@ def check_merge_helpers(threads):
         if chain:
             assert L.s2s_blow5_scan(cfd, 4, 4 + len(chain) - 1) == -2          # the last record runs past the end
         assert L.s2s_blow5_scan(cfd, 4, 3) < 0 and L.s2s_blow5_scan(-1, 0, 0) < 0
+        # the walk over a file "still being written": any limit inside the chain yields the complete records in front of it
+        ends = np.cumsum([0] + [8 + z for z in sizes]) + 4
+        for _ in range(6):
+            limit = int(rng.integers(0, 4 + len(chain) + 6 + 1))
+            cap = int(rng.integers(0, len(sizes) + 3))
+            out_end = Buf(n=8)
+            got = L.s2s_blow5_scan_upto(cfd, 4, limit, cap, out_end.p)
+            want = min(cap, int(np.searchsorted(ends, limit, side="right")) - 1) if limit >= 4 else 0
+            want = max(want, 0)
+            # (the 5-byte end marker behind the chain never counts: it is shorter than a size prefix, or its "size" runs past the limit)
+            assert got == want, (got, want, limit, cap, sizes)
+            assert np.frombuffer(out_end.bytes(), np.int64)[0] == ends[got]
+            out_end.free()
         for fd in [x[0] for x in srcs] + [dst, cfd]:
             os.close(fd)
 
