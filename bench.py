@@ -521,9 +521,9 @@ def one_command(mode, world, n_total, fasta, td, join="after"):
            os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"), "--compute-mode", mode, "-v", "warning"] + (["--join", join] if join != "after" else [])
     t0 = time.perf_counter()
     try:
-        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=110)   # (both joins fit the leg's 300-s barrier)
     except subprocess.TimeoutExpired:
-        return {"error": "timed out after 200 s", "cmd": " ".join(cmd[1:])}
+        return {"error": "timed out after 110 s", "cmd": " ".join(cmd[1:])}
     seconds = time.perf_counter() - t0
     if p.returncode != 0:
         return {"error": f"exit code {p.returncode}: {(p.stderr or p.stdout)[-400:]}", "cmd": " ".join(cmd[1:])}
