@@ -520,13 +520,21 @@ def one_command(mode, world, n_total, fasta, td, join="after"):
            os.path.join(td, "cmd.blow5"), "--gpus", str(world), "--seed", "42", "-m",
            os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"), "--compute-mode", mode, "-v", "warning"] + (["--join", join] if join != "after" else [])
     t0 = time.perf_counter()
+    # its own process group: on a timeout the command AND the ranks it started are ended (by that group id), nothing is orphaned on a GPU
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=110)   # (both joins fit the leg's 300-s barrier)
+        stdout, stderr = proc.communicate(timeout=110)            # (both joins fit the leg's 300-s barrier)
     except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.communicate()
         return {"error": "timed out after 110 s", "cmd": " ".join(cmd[1:])}
     seconds = time.perf_counter() - t0
-    if p.returncode != 0:
-        return {"error": f"exit code {p.returncode}: {(p.stderr or p.stdout)[-400:]}", "cmd": " ".join(cmd[1:])}
+    if proc.returncode != 0:
+        return {"error": f"exit code {proc.returncode}: {(stderr or stdout)[-400:]}", "cmd": " ".join(cmd[1:])}
     out = {"cmd": "python " + " ".join(cmd[1:]).replace(ROOT + os.sep, "").replace(td + os.sep, "OUT/"), "seconds": seconds,
            "reads_per_sec": n_total / seconds, "output_bytes": os.path.getsize(os.path.join(td, "cmd.blow5"))}
     try:
