@@ -135,57 +135,65 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
                 holder["live"].abort()          # (a rank file the live join could not make sense of: no partial output stays behind)
             raise
         live = holder.get("live") if make_live is not None else None
-        timing["ranks_seconds"] = time.time() - t0
-        if live is not None:
-            if rc == 0:
-                t1 = time.time()
-                try:
-                    n, st = live.finish(consume=True)
-                    os.replace(live.out, str(out))
-                except BaseException:
-                    live.abort()
-                    raise
-                timing.update(merge_seconds=time.time() - t1, merge_bytes=st["bytes"], merge_bytes_copied=st["bytes"], reads=n, join="live",
-                              live_bytes=st["live_bytes"], live_copy_seconds=st["copy_seconds"], join_order=st["order"])
-                click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {round(timing.get('launch_seconds', 0), 2)} s, ranks "
-                           f"{timing['ranks_seconds']:.2f} s in all with {st['live_bytes'] / 1e9:.2f} of {st['bytes'] / 1e9:.2f} GB joined meanwhile, "
-                           f"{timing['merge_seconds']:.2f} s to finish the file; {st['order']}]")
-            else:
-                live.abort()
-        elif rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
-            # one output file, as the reference writes (inference.py:65-79): the first rank's file becomes OUT, the payload of the
-            # others moves in as byte ranges on copy threads (merge.py), the rank files are gone afterwards
-            from .parallel import rank_output_path
-            from .signal_io import merge_shards as _merge
-            shards = [rank_output_path(str(out), r, gpus) for r in range(gpus)]
-            t1 = time.time()
-            n = _merge(shards, str(out), consume=True)
-            timing["merge_seconds"] = time.time() - t1
-            timing["merge_bytes"] = _merge.last.get("bytes", 0)
-            timing["merge_bytes_copied"] = _merge.last.get("bytes_copied", 0)
-            timing["reads"] = n
-            launch = timing.get("launch_seconds")
-            click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {launch if launch is None else round(launch, 2)} s, "
-                       f"ranks {timing['ranks_seconds']:.2f} s in all, merge {timing['merge_seconds']:.2f} s for "
-                       f"{timing['merge_bytes'] / 1e9:.2f} GB]")
-        late = reap()                                       # (the merge did not wait for the ranks' teardown: see _launch_ranks)
-        rc = rc or late
-        timing["total_seconds"] = time.time() - t0
         try:
-            import resource
-            # (the peak counts the tmpfs pages of the output while they are mapped for the fill -- one shard's span, shared memory that
-            #  belongs to the file, not to this process; what the process itself holds is the anonymous part)
-            timing["parent_peak_rss_mb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
-            for line in open("/proc/self/status"):
-                if line.startswith("RssAnon:"):
-                    timing["parent_anon_rss_mb"] = int(line.split()[1]) / 1024.0
-        except (ImportError, OSError):
-            pass
-        if os.environ.get("S2S_TIMING_JSON") and not os.environ.get("S2S_DRY_LAUNCH"):
-            import json
-            with open(os.environ["S2S_TIMING_JSON"], "w") as f:
-                json.dump(timing, f)
+            timing["ranks_seconds"] = time.time() - t0
+            if live is not None:
+                if rc == 0:
+                    t1 = time.time()
+                    try:
+                        n, st = live.finish(consume=True)
+                        os.replace(live.out, str(out))
+                    except BaseException:
+                        live.abort()
+                        raise
+                    timing.update(merge_seconds=time.time() - t1, merge_bytes=st["bytes"], merge_bytes_copied=st["bytes"], reads=n, join="live",
+                                  live_bytes=st["live_bytes"], live_copy_seconds=st["copy_seconds"], join_order=st["order"])
+                    click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {round(timing.get('launch_seconds', 0), 2)} s, ranks "
+                               f"{timing['ranks_seconds']:.2f} s in all with {st['live_bytes'] / 1e9:.2f} of {st['bytes'] / 1e9:.2f} GB joined meanwhile, "
+                               f"{timing['merge_seconds']:.2f} s to finish the file; {st['order']}]")
+                else:
+                    live.abort()
+            elif rc == 0 and not keep_shards and not os.environ.get("S2S_DRY_LAUNCH"):
+                # one output file, as the reference writes (inference.py:65-79): the first rank's file becomes OUT, the payload of the
+                # others moves in as byte ranges on copy threads (merge.py), the rank files are gone afterwards
+                from .parallel import rank_output_path
+                from .signal_io import merge_shards as _merge
+                shards = [rank_output_path(str(out), r, gpus) for r in range(gpus)]
+                t1 = time.time()
+                n = _merge(shards, str(out), consume=True)
+                timing["merge_seconds"] = time.time() - t1
+                timing["merge_bytes"] = _merge.last.get("bytes", 0)
+                timing["merge_bytes_copied"] = _merge.last.get("bytes_copied", 0)
+                timing["reads"] = n
+                launch = timing.get("launch_seconds")
+                click.echo(f"{n} reads from {gpus} ranks -> {out}  [launch {launch if launch is None else round(launch, 2)} s, "
+                           f"ranks {timing['ranks_seconds']:.2f} s in all, merge {timing['merge_seconds']:.2f} s for "
+                           f"{timing['merge_bytes'] / 1e9:.2f} GB]")
+            late = reap()                                       # (the merge did not wait for the ranks' teardown: see _launch_ranks)
+            rc = rc or late
+            timing["total_seconds"] = time.time() - t0
+            try:
+                import resource
+                # (the peak counts the tmpfs pages of the output while they are mapped for the fill -- one shard's span, shared memory that
+                #  belongs to the file, not to this process; what the process itself holds is the anonymous part)
+                timing["parent_peak_rss_mb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+                for line in open("/proc/self/status"):
+                    if line.startswith("RssAnon:"):
+                        timing["parent_anon_rss_mb"] = int(line.split()[1]) / 1024.0
+            except (ImportError, OSError):
+                pass
+            if os.environ.get("S2S_TIMING_JSON") and not os.environ.get("S2S_DRY_LAUNCH"):
+                import json
+                with open(os.environ["S2S_TIMING_JSON"], "w") as f:
+                    json.dump(timing, f)
+        except BaseException:
+            reap(force=True)                    # (a failed join: no rank process and no s2s-ranks-* directory stays behind)
+            raise
         ctx.exit(rc)
+    # a rank of a multi-process run binds itself to its share of its GPU's socket FIRST: before torch starts its thread pools,
+    # before the first page of a pinned staging buffer is touched (placement.pin_rank; S2S_NO_PIN=1 opts out)
+    from .placement import pin_rank
+    pinned = pin_rank()
     from .inference import inference_run
     from .utils import set_seeds, setup_logging
 
@@ -199,6 +207,9 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
         ctx.exit(1)
     setup_logging(verbosity)
     logger.info("seq2squiggle (MI355X engine) version %s", str(__version__))
+    if pinned:
+        logger.debug(f"rank {os.environ.get('RANK', '0')}: bound to CPUs {pinned['cpus']} ({pinned['source']}"
+                     + (f": NUMA node {pinned['numa_node']} of GPU {pinned['bdf']}" if pinned["source"] == "sysfs" else "") + ")")
     cfg = set_config(config)
     import time
     t_ready = time.time()                      # interpreter, torch and the library are loaded: what a rank pays before its first read
@@ -228,7 +239,7 @@ def predict(ctx, fasta, read_input, num_reads, read_length, coverage, out, profi
         os._exit(0)
 
 
-def _launch_ranks(gpus: int, make_live=None):
+def _launch_ranks(gpus: int, make_live=None, cmd=None):
     """`predict --gpus N` outside torchrun: the same command line once per GPU, as N CHILD processes of this one (which never touches
     the GPU) with the environment torchrun would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1,
     MASTER_PORT) -- started directly: the elastic agent of torch.distributed.run costs an import of torch in the parent and a
@@ -259,18 +270,62 @@ def _launch_ranks(gpus: int, make_live=None):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "seq2squiggle_amd"] + argv
-    rank_env = lambda r: {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "LOCAL_WORLD_SIZE": str(gpus),
-                          "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    cmd = cmd or [sys.executable, "-m", "seq2squiggle_amd"] + argv       # (cmd: the supervision tests start stand-in ranks)
+    from .placement import rank_visibility, visible_list
+    parent_visible = visible_list()
+
+    def rank_env(r):
+        # one device per rank (HIP_VISIBLE_DEVICES = the r-th device this process may see): a rank cannot place anything on a
+        # neighbour's GPU, whatever a call site passes; S2S_PARENT_VISIBLE lets every rank work out the same CPU table (placement.pin_rank)
+        return {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "LOCAL_WORLD_SIZE": str(gpus),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "S2S_PARENT_VISIBLE": ",".join(parent_visible) if parent_visible is not None else "", **rank_visibility(r)}
     if os.environ.get("S2S_DRY_LAUNCH"):
         click.echo(json.dumps({"dry_launch": cmd, "rank_env": [rank_env(r) for r in range(gpus)]}))
-        return 0, {}, lambda: 0
+        return 0, {}, lambda force=False: 0
     timing_dir = tempfile.mkdtemp(prefix="s2s-ranks-")
     base = dict(os.environ, S2S_TIMING_DIR=timing_dir)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     t0 = time.time()
-    procs = [subprocess.Popen(cmd, env=dict(base, **rank_env(r))) for r in range(gpus)]
+    import signal
+
+    class _Ended(BaseException):
+        """SIGTERM / SIGHUP to the launcher: unwinds through the handlers below, which end the ranks."""
+
+    def _on_signal(signum, frame):
+        raise _Ended(signum)
+    old_handlers = {}
+    for sig in (signal.SIGTERM, signal.SIGHUP):
+        try:                                     # (only the main thread may install handlers: tests call this from there too)
+            old_handlers[sig] = signal.signal(sig, _on_signal)
+        except (ValueError, OSError):
+            pass
+    procs = []
+    try:
+        for r in range(gpus):
+            procs.append(subprocess.Popen(cmd, env=dict(base, **rank_env(r))))
+    except BaseException:
+        for p_ in procs:
+            p_.kill()
+        raise
     rc = 0
+
+    def end_ranks(which, grace=float(os.environ.get("S2S_RANK_GRACE", "10"))):
+        """terminate(), then kill() for whoever has not left after `grace` seconds (a rank stuck in a HIP call ignores SIGTERM)."""
+        alive = [procs[q] for q in which if procs[q].poll() is None]
+        for p_ in alive:
+            p_.terminate()
+        deadline = time.time() + grace
+        for p_ in alive:
+            try:
+                p_.wait(timeout=max(0.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+        for p_ in alive:
+            try:
+                p_.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
 
     def stamps():
         try:
@@ -279,16 +334,25 @@ def _launch_ranks(gpus: int, make_live=None):
         except (OSError, ValueError):
             return []
 
-    def reap() -> int:
+    def reap(force: bool = False) -> int:
         """Waits for the ranks that are still shutting down (interpreter, torch and HIP teardown: ~0.3 s each, which the merge
-        does not have to wait for) -> the first non-zero exit code, or 0."""
+        does not have to wait for) -> the first non-zero exit code, or 0.  force: the command is failing -- end them now.
+        Idempotent; also gives the signal handlers back and removes the stamp directory."""
         code = 0
+        if force:
+            end_ranks(range(len(procs)))
         for p_ in procs:
             try:
                 code = code or p_.wait(timeout=120)
             except subprocess.TimeoutExpired:
                 p_.kill()
                 code = code or 1
+        for sig, h in old_handlers.items():
+            try:
+                signal.signal(sig, h)
+            except (ValueError, OSError):
+                pass
+        old_handlers.clear()
         shutil.rmtree(timing_dir, ignore_errors=True)
         return code
     live = None
@@ -318,14 +382,11 @@ def _launch_ranks(gpus: int, make_live=None):
                 if code != 0 and rc == 0:
                     rc = code
                     logger.error(f"rank {r} exited with code {code}; ending the other ranks")
-                    for q in left:
-                        procs[q].terminate()
+                    end_ranks(sorted(left))
             if left and not moved:
                 time.sleep(0.005)
     except BaseException:
-        for p_ in procs:
-            if p_.poll() is None:
-                p_.kill()
+        reap(force=True)
         raise
     timing = {}
     rows = stamps() if rc == 0 else []

@@ -44,6 +44,65 @@ def get_writer(out: str, profile: object, ideal_mode: bool, export_every_n_sampl
     raise ValueError("Output file must have .pod5, .slow5, or .blow5 extension.")
 
 
+REFERENCE_VERSION = "0.3.4"        # the release of the reference this engine mirrors (pyproject.toml): the `@vX.Y.Z` its cache is searched for
+
+
+def user_cache_dir(appname: str = "seq2squiggle") -> str:
+    """appdirs.user_cache_dir(appname, False, opinion=False) on Linux, without the dependency: $XDG_CACHE_HOME (default ~/.cache) /
+    appname -- the directory the reference keeps its downloaded weights in (inference.py:104)."""
+    return os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.expanduser("~/.cache"), appname)
+
+
+def get_saved_weights(profile_name: str, version: str = REFERENCE_VERSION) -> str:
+    """The cache half of the reference's get_saved_weights (inference.py:85-149): when `-m` is omitted, look in the reference's own
+    cache directory for `<name>@vX.Y.Z.ckpt` files of this chemistry ("R10" / "R9" in the file name, by --profile) and return the
+    best version match -- what a reference user with downloaded weights runs offline today.  The download half (inference.py:151-221)
+    needs the network and stays out of scope: with no match this raises FileNotFoundError naming the directory searched.
+
+    The loop is the reference's, quirks included, so that the same cache yields the same file: `version` is the version STRING, so
+    `zip(version, file_version)` pairs its characters '0', '.', '3' with the file's (major, minor, patch) -- a file scores 1 for an
+    equal major plus 1 when its patch equals the minor's digit, candidates are visited in os.listdir order and only a strictly
+    better score replaces the pick; a profile with neither keyword (rna-004-*) never matches a cached file.  One deliberate
+    difference: a `.ckpt` without `@vX.Y.Z` in its name is skipped (the reference's loop dies on it with an AttributeError)."""
+    import re
+    logger.info("Weights file path is not provided.")
+    cache_dir = user_cache_dir("seq2squiggle")
+    if profile_name.startswith("dna-r10"):
+        logger.info("Detected R10.4.1 chemistry profile.")
+        logger.info("Profile can be changed with the --profile parameter")
+        profile_keyword = "R10"
+    elif profile_name.startswith("dna-r9"):
+        logger.info("Detected R9.4.1 chemistry profile.")
+        logger.info("Profile can be changed with the --profile parameter")
+        profile_keyword = "R9"
+    else:
+        logger.warning("Profile name '%s' does not match known patterns (R10- or R9-). Proceeding with latest weights.", profile_name)
+        profile_keyword = None
+    best, best_score = None, 0
+    try:
+        os.makedirs(cache_dir, exist_ok=True)                  # (inference.py:105)
+        names = os.listdir(cache_dir)
+    except OSError:
+        names = []
+    for filename in names:
+        root, ext = os.path.splitext(filename)
+        if ext != ".ckpt":
+            continue
+        m = re.match(r".*@v(\d+).(\d+).(\d+)", root)
+        if m is None:
+            logger.debug(f"{filename}: no @vX.Y.Z in the name, skipped")
+            continue
+        same = [i == j for i, j in zip(version, m.groups())]
+        score = sum(same) if same[0] else 0
+        if score > best_score and profile_keyword and profile_keyword in root:
+            best, best_score = os.path.join(cache_dir, filename), score
+    if best_score > 0:
+        logger.info("Found matching weights in local cache: %s", best)
+        return best
+    raise FileNotFoundError(f"no model weights given and none for profile {profile_name} (release v{version}) in the cache directory "
+                            f"{cache_dir}: downloading released weights needs network access; pass --model <file.ckpt>")
+
+
 _EXCLUDE = ("log_name", "wandb_logger_state", "max_chunks_train", "max_chunks_valid", "train_valid_split",
             "train_batch_size", "save_model")
 
@@ -378,12 +437,15 @@ def inference_run(config: dict, saved_weights: str, fasta: str, read_input: bool
                                                 export_every_n_samples, profile_name=profile,
                                                 preserve_read_ids=preserve_read_ids)
     if saved_weights is None:
-        raise FileNotFoundError("no model weights given: downloading released weights needs network access; pass "
-                                "--model <file.ckpt>")
+        saved_weights = get_saved_weights(profile)             # (inference.py:370-372; the cache only: no network here)
     first_chunk, first_read, total_l = 0, 0, 0
     if world > 1 and not seed:
         raise ValueError("multi-process runs need one seed for all ranks: pass an explicit --seed, or let the CLI share a "
                          "fresh one (parallel.shared_seed) before calling inference_run")
+    # belt and braces for a user's own torchrun (all devices visible): whatever allocates without naming a device -- a pinned buffer's
+    # primary-context search, a library call -- lands on this rank's GPU.  Children of `predict --gpus N` see one device only.
+    if torch.cuda.is_available():              # (without a GPU the engine's constructor is what raises, with its own message)
+        torch.cuda.set_device(local_rank)
     # the checkpoint is read and the engine created (weight re-packing, device allocations: native code, no interpreter lock)
     # on a helper thread while this one parses the FASTA and samples the reads
     from concurrent.futures import ThreadPoolExecutor

@@ -15,9 +15,12 @@ def rank_world() -> Tuple[int, int, int]:
 
 
 def local_device() -> int:
-    """The GPU of this rank: LOCAL_RANK (one process per GPU).  S2S_ONE_GPU=1 puts every rank on GPU 0 -- a rehearsal of the
-    multi-process path on a one-GPU box (the ranks then share the device; there is no data-path collective to object)."""
-    return 0 if os.environ.get("S2S_ONE_GPU") else rank_world()[1]
+    """The GPU of this rank as ITS process numbers it: 0 when the process sees one device only -- a child of `predict --gpus N`,
+    whose launcher narrows HIP_VISIBLE_DEVICES per rank (placement.rank_visibility) -- else LOCAL_RANK (a user's own torchrun,
+    all devices visible).  S2S_ONE_GPU=1 puts every rank on GPU 0: a rehearsal of the multi-process path on a one-GPU box (the
+    ranks then share the device; there is no data-path collective to object)."""
+    from .placement import local_device as _ld
+    return _ld()
 
 
 def shard_reads(read_lens: Sequence[int], k: int, world: int) -> List[Tuple[int, int, int]]:

@@ -87,7 +87,10 @@ def cpu_share() -> int:
     a stall of tens of milliseconds), divided between the ranks of a multi-process run on this node."""
     if os.environ.get("S2S_CPU_SHARE"):                # explicit override (tools/host_scaling.py: what if a rank only gets n threads?)
         return max(1, int(os.environ["S2S_CPU_SHARE"]))
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     cores = len(os.sched_getaffinity(0))
+    if os.environ.get("S2S_PINNED_CPUS"):              # placement.pin_rank has narrowed the mask to this rank's share already
+        cores *= ranks
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:                          # cgroup v2: "<quota> <period>" | "max <period>"
             quota, period = f.read().split()[:2]
@@ -101,7 +104,7 @@ def cpu_share() -> int:
                 cores = min(cores, max(1, quota // period))
         except (OSError, ValueError):
             pass
-    return max(1, min(128, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    return max(1, min(128, cores // ranks))
 
 
 class BLOW5Writer:

@@ -737,6 +737,83 @@ def test_launch_ranks_collects_timing_and_ends_siblings_on_failure(tmp_path, mon
     reap()
 
 
+_STUBBORN_RANK = r"""
+import os, signal, sys, time
+# a rank stuck where SIGTERM does not reach it (a HIP call that never returns): only SIGKILL ends it
+rank = int(os.environ["RANK"])
+open(os.path.join(os.environ["STUB_DIR"], "pid%d" % rank), "w").write(str(os.getpid()))
+if rank == 0 and os.environ.get("STUB_MODE") == "fail":
+    time.sleep(0.3)
+    sys.exit(5)
+signal.signal(signal.SIGTERM, signal.SIG_IGN)
+time.sleep(120)
+"""
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    try:                                               # (a zombie that nobody has waited for yet still answers signal 0)
+        return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_launcher_kills_a_rank_that_ignores_sigterm(tmp_path, monkeypatch):
+    """after one rank fails the siblings get terminate() -- and, after a grace period, kill(): a rank stuck in a device
+    call must not hang the command."""
+    import time
+    from seq2squiggle_amd import cli
+    stub = tmp_path / "stubborn.py"
+    stub.write_text(_STUBBORN_RANK)
+    monkeypatch.setenv("STUB_DIR", str(tmp_path))
+    monkeypatch.setenv("STUB_MODE", "fail")
+    monkeypatch.setenv("S2S_RANK_GRACE", "1")
+    monkeypatch.delenv("S2S_DRY_LAUNCH", raising=False)
+    t0 = time.time()
+    rc, timing, reap = cli._launch_ranks(3, cmd=[sys.executable, str(stub)])
+    assert rc == 5 and timing == {} and time.time() - t0 < 30
+    reap()
+    pids = [int(open(tmp_path / f"pid{r}").read()) for r in range(3)]
+    assert not any(_alive(p) for p in pids)
+    assert not [d for d in os.listdir(__import__("tempfile").gettempdir()) if d.startswith("s2s-ranks-")
+                and os.stat(os.path.join(__import__("tempfile").gettempdir(), d)).st_mtime >= t0 - 1]
+
+
+_LAUNCHER_UNDER_SIGNAL = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from seq2squiggle_amd import cli
+open(os.path.join(os.environ["STUB_DIR"], "parent"), "w").write(str(os.getpid()))
+cli._launch_ranks(2, cmd=[sys.executable, sys.argv[2]])
+"""
+
+
+def test_sigterm_to_the_launcher_ends_its_ranks(tmp_path):
+    """SIGTERM / SIGHUP to the parent of `predict --gpus N` must not leave N ranks orphaned on their GPUs."""
+    import signal
+    import time
+    stub = tmp_path / "stubborn.py"
+    stub.write_text(_STUBBORN_RANK)
+    parent = tmp_path / "parent.py"
+    parent.write_text(_LAUNCHER_UNDER_SIGNAL)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "S2S_DRY_LAUNCH")}
+    env.update(STUB_DIR=str(tmp_path), STUB_MODE="hang", S2S_RANK_GRACE="1")
+    p = subprocess.Popen([sys.executable, str(parent), ROOT, str(stub)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / f"pid{r}").exists() and (tmp_path / f"pid{r}").read_text() for r in range(2)):
+        time.sleep(0.05)
+    pids = [int((tmp_path / f"pid{r}").read_text()) for r in range(2)]
+    assert all(_alive(x) for x in pids)
+    p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=60)
+    assert p.returncode != 0
+    time.sleep(0.2)
+    assert not any(_alive(x) for x in pids)
+
+
 _SEED_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
