@@ -5,8 +5,10 @@ A "step" is one pass of the hot path (s2s_predict_chunks: the fused frontend + d
 per step -- a launch takes up to 2^20 chunks) over one batch of synthetic reads already resident in HBM.  Workload at N=1 (BASELINE.json configs[1]
 shape): 1000 reads x 5000 nt = 312,000 chunks, default noise + duration samplers (noise_std 2.0,
 min_duration 3), synthetic k=9 checkpoint.  With N>1 every rank runs the same amount of work on
-its own read shard (weak scaling, no data-path collective); RCCL is used only for the barrier
-and the max-over-ranks of the elapsed time.
+its own read shard (weak scaling, no data-path collective).  The path has no exchange step, so the bench needs no RCCL:
+the barrier around the timed region, the max-over-ranks and the per-rank gather run on a HOST (gloo) group, each side of a
+torch.cuda.synchronize().  RCCL is a reported self-test (`rccl_selftest`: N throw-away child processes, wall-limited, started
+after the timed region so that nothing it does can cost the measurement), not a dependency.
 
 `python bench.py --gpus N` without a torchrun environment starts its N ranks itself, as CHILD processes
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`), before
@@ -49,16 +51,18 @@ def make_reads(n_reads, seed):
     return [lut[c].tobytes().decode() for c in codes]
 
 
-def pmc_counters(mode, chunks_per_launch):
+def pmc_counters(mode, chunks_per_launch, root=None):
     """From the newest committed PMC passes (tools/pmc_run.sh -> profiles/*/pmc_summary.json), for the decoder kernel:
     HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half of a wide coalesced read on
     gfx950 (MI355X_MICROARCH.md, HBM) -- measured on one full dispatch and scaled to this run's launch size; matrix-core
     busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; vector issue fraction =
     4 x SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 over the same cycles."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json")), reverse=True):
+    root = root or ROOT
+    for path in sorted(glob.glob(os.path.join(root, "profiles", "*", "pmc_summary.json")), reverse=True):
         try:
-            d = json.load(open(path)).get(mode, {})
+            whole = json.load(open(path))
+            d = whole.get(mode, {})
             k = max((k for k in d if "fused" in k), key=lambda k: d[k].get("_launch", {}).get("chunks", 0))   # (not the 512-chunk calibration launch)
             c = d[k]
             chunks = c.get("_launch", {}).get("chunks", 32768)
@@ -70,11 +74,48 @@ def pmc_counters(mode, chunks_per_launch):
             except Exception:
                 pass
             return {"traffic": per_chunk * chunks_per_launch, "mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
-                    "valu_issue": 4 * c["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, "source": os.path.relpath(path, ROOT),
-                    "effective_clock_ghz": c.get("_effective_clock_ghz"), "in_kernel_clock": clock}
+                    "valu_issue": 4 * c["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, "source": os.path.relpath(path, root),
+                    "effective_clock_ghz": c.get("_effective_clock_ghz"), "in_kernel_clock": clock,
+                    "extra": dict(pmc_staleness(whole.get("_meta")), **mfma_issue_fields(mode, c, chunks))}
         except Exception:
             continue
-    return {"traffic": None, "mfma_busy": None, "valu_issue": None, "source": None, "effective_clock_ghz": None, "in_kernel_clock": None}
+    return {"traffic": None, "mfma_busy": None, "valu_issue": None, "source": None, "effective_clock_ghz": None, "in_kernel_clock": None,
+            "extra": {"pmc_stale": None}}
+
+
+def pmc_staleness(meta):
+    """Do the committed counters describe the kernel source that is running?  tools/pmc_run.sh records the sha256 of the library's
+    sources (_build.source_hash) beside the passes, tools/pmc_summarize.py carries it into pmc_summary.json with the git commit;
+    here it is compared with the sources of THIS tree.  -> pmc_stale true | false | None (a summary from before round 6: no hash)."""
+    from seq2squiggle_amd import _build
+    now = _build.source_hash()
+    then = (meta or {}).get("csrc_sha256")
+    return {"pmc_stale": None if not then else then != now, "pmc_csrc_sha256": then, "csrc_sha256": now,
+            "pmc_git_commit": (meta or {}).get("git_commit")}
+
+
+MFMA_FLOP = {"16x16x32_f16": 2 * 16 * 16 * 32, "32x32x16_f16": 2 * 32 * 32 * 16, "16x16x4_f32": 2 * 16 * 16 * 4}
+
+
+def mfma_issue_fields(mode, c, chunks):
+    """What the matrix pipe was ASKED to do per chunk, from the instruction counters of the profiled launch: SQ_INSTS_VALU_MFMA_MOPS_*
+    counts issued matrix math in units of 512 operations (a full EXEC mask), SQ_INSTS_MFMA the wave instructions; with two shapes in
+    the kernel (f16: 16x16x32 for the GEMMs, 32x32x16 for the attention core) the two counts give the split.  mfma_useful_frac =
+    algorithmic FLOP / issued FLOP: the rest is padding (phantom keys, unused A rows of the P.V product, the hi / lo stacking)."""
+    mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32" if mode == "f32" else "SQ_INSTS_VALU_MFMA_MOPS_F16")
+    n = c.get("SQ_INSTS_MFMA")
+    if not mops or not n or not chunks:
+        return {"mfma_issued_flop_per_chunk": None, "mfma_useful_frac": None}
+    issued = 512.0 * mops / chunks
+    out = {"mfma_issued_flop_per_chunk": issued, "mfma_useful_frac": FLOP_PER_CHUNK / issued,
+           "mfma_wave_instructions_per_chunk": n / chunks}
+    if mode != "f32":
+        # n16 + n32 = n;  16384 n16 + 32768 n32 = 512 mops
+        n32 = (512.0 * mops - MFMA_FLOP["16x16x32_f16"] * n) / (MFMA_FLOP["32x32x16_f16"] - MFMA_FLOP["16x16x32_f16"])
+        out["mfma_by_shape_per_chunk"] = {"16x16x32_f16": (n - n32) / chunks, "32x32x16_f16": n32 / chunks}
+        out["mfma_useful_frac_note"] = ("algorithmic FLOP over issued FLOP; of the issued, 1/3 at most is algorithmic in the three-product "
+                                        "split, the rest of the gap is padding")
+    return out
 
 
 def _e2e_dirs():
@@ -323,7 +364,7 @@ def weight_sensitivity_leg(mode, bases_d, nv_d, sig, dur, params, steps):
             "min_chunks_per_sec": min(rates), "max_chunks_per_sec": max(rates)}
 
 
-def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
+def cpu_baseline(sd, cfg, eng, seconds_target=12.0, sample_chunks=1024):
     """Oracle (CPU port of the reference op sequence, torch fp32 'highest') on the host cores, plus a live parity
     check of the engine against it on the first 256 chunks of the sample (injected variates)."""
     from oracle import s2s_oracle as O
@@ -331,10 +372,10 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
     torch.set_float32_matmul_precision("highest")
     torch.set_num_threads(cpu_share())      # the cores this container may actually keep busy (cgroup quota), not the host's count
     reads = make_reads(4, 99)
-    codes = np.concatenate([O.encode_read(r, cfg["seq_kmer"]) for r in reads], 0)[:1024]
+    codes = np.concatenate([O.encode_read(r, cfg["seq_kmer"]) for r in reads], 0)[:sample_chunks]
     p = O.PredictParams()
     gen = torch.Generator().manual_seed(0)
-    O.predict_chunks(sd, cfg, codes[:64], p, generator=gen)            # warm-up
+    O.predict_chunks(sd, cfg, codes[:min(64, sample_chunks)], p, generator=gen)            # warm-up
     t0, done = time.perf_counter(), 0
     while True:
         O.predict_chunks(sd, cfg, codes, p, generator=gen)
@@ -342,6 +383,9 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
         el = time.perf_counter() - t0
         if el >= seconds_target or done >= 8 * 1024:
             break
+    if seconds_target < 1.0:                               # (self-test: no second timing pass)
+        return {"value": done * 250 / el, "unit": "samples/s", "cores": torch.get_num_threads(), "parity": None, "kind": "port",
+                "sample": f"{done} chunks in {el:.1f} s (launcher self-test)"}
     # the reference ships torch.set_float32_matmul_precision("medium") (model.py:22): time that too (bf16-capable CPUs
     # may take a faster, less exact matmul path); parity is only ever claimed against "highest"
     torch.set_float32_matmul_precision("medium")
@@ -353,22 +397,24 @@ def cpu_baseline(sd, cfg, eng, seconds_target=12.0):
         if el_m >= seconds_target / 3 or done_m >= 3 * 1024:
             break
     torch.set_float32_matmul_precision("highest")
-    n = 256
-    g = torch.rand(n, 16, generator=gen) * 20
-    z = torch.randn(n, 250, generator=gen)
-    ref = O.predict_chunks(sd, cfg, codes[:n], p, inject_g=g, inject_z01=z)
-    from seq2squiggle_amd import chunker
-    b_, nv_ = chunker.codes_to_bases(codes[:n])
-    got = eng.predict_chunks(torch.from_numpy(b_).to(eng.device), torch.from_numpy(nv_).to(eng.device), S.PredictParams(),
-                             inject_g=g.to(eng.device), inject_z01=z.to(eng.device))
-    y, r = got["signal"].cpu().numpy(), ref["signal"].numpy()
-    parity = {"chunks": n, "signal_mae_pa": float(np.abs(y - r).mean()), "signal_max_abs_pa": float(np.abs(y - r).max()),
-              "dwell_indices_equal": bool(np.array_equal(got["dur"].cpu().numpy(), ref["dur"].numpy())),
-              "zero_pattern_equal": bool(np.array_equal(y == 0, r == 0)), "tolerance_mae_pa": 1e-4}
+    parity = None
+    if eng is not None:                                    # (the launcher's CPU self-test times the oracle without an engine)
+        n = 256
+        g = torch.rand(n, 16, generator=gen) * 20
+        z = torch.randn(n, 250, generator=gen)
+        ref = O.predict_chunks(sd, cfg, codes[:n], p, inject_g=g, inject_z01=z)
+        from seq2squiggle_amd import chunker
+        b_, nv_ = chunker.codes_to_bases(codes[:n])
+        got = eng.predict_chunks(torch.from_numpy(b_).to(eng.device), torch.from_numpy(nv_).to(eng.device), S.PredictParams(),
+                                 inject_g=g.to(eng.device), inject_z01=z.to(eng.device))
+        y, r = got["signal"].cpu().numpy(), ref["signal"].numpy()
+        parity = {"chunks": n, "signal_mae_pa": float(np.abs(y - r).mean()), "signal_max_abs_pa": float(np.abs(y - r).max()),
+                  "dwell_indices_equal": bool(np.array_equal(got["dur"].cpu().numpy(), ref["dur"].numpy())),
+                  "zero_pattern_equal": bool(np.array_equal(y == 0, r == 0)), "tolerance_mae_pa": 1e-4}
     return {"value": done * 250 / el, "unit": "samples/s", "cores": torch.get_num_threads(), "parity": parity,
             "host_logical_cpus": len(os.sched_getaffinity(0)), "cpu_quota": cpu_share(), "kind": "port",
             "reads_per_sec": done / CHUNKS_PER_READ / el, "value_matmul_precision_medium": done_m * 250 / el_m,
-            "sample": f"{done} chunks (batches of 1024, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
+            "sample": f"{done} chunks (batches of {sample_chunks}, same 5 kb synthetic reads, default samplers) in {el:.1f} s"}
 
 
 def end_to_end_sharded(mode, dist, rank, world, dev):
@@ -545,6 +591,161 @@ def one_command(mode, world, n_total, fasta, td, join="after"):
     return out
 
 
+class HostGroup:
+    """The ranks' meeting point: a gloo process group on host tensors (no GPU, no RCCL).  One rank: every call is a no-op."""
+
+    def __init__(self, world, timeout_s=900):
+        self.world, self.dist = world, None
+        if world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST"):
+            from datetime import timedelta
+            import torch.distributed as dist
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: never resolve the container's hostname
+            dist.init_process_group("gloo", timeout=timedelta(seconds=timeout_s))
+            self.dist = dist
+
+    @property
+    def backend(self):
+        return "gloo" if self.dist else None
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max(self, x):
+        if not self.dist:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        if not self.dist:
+            return [obj]
+        rows = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(rows, obj)
+        return rows
+
+    def size(self):
+        return self.dist.get_world_size() if self.dist else 1
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def device_identity(index):
+    """What tells two GPUs apart: PCI address and uuid of device `index` as this process numbers it (None off the GPU)."""
+    if index is None or not torch.cuda.is_available():
+        return None
+    p = torch.cuda.get_device_properties(index)
+    out = {"index": index, "name": p.name}
+    try:
+        out["pci"] = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    except AttributeError:
+        out["pci"] = None
+    try:
+        out["uuid"] = str(p.uuid)
+    except Exception:
+        out["uuid"] = None
+    return out
+
+
+def devices_distinct(rows):
+    """True when every rank reported another GPU (by PCI address, else uuid); None when nobody could tell."""
+    keys = [(r or {}).get("pci") or (r or {}).get("uuid") for r in rows]
+    if any(k is None for k in keys):
+        return None
+    return len(set(keys)) == len(keys)
+
+
+def rccl_selftest_child():
+    """One rank of the RCCL self-test (a fresh process that does nothing else): init_process_group("nccl"), one all_reduce of ones
+    on its device; rank 0 prints {"ok", "sum", "init_seconds", "allreduce_seconds"}."""
+    if os.environ.get("S2S_BENCH_SELFTEST_HANG"):            # (tests: a child that never comes back must be killed and reported)
+        time.sleep(3600)
+    import torch.distributed as dist
+    from seq2squiggle_amd.placement import local_device
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", local_device())
+    torch.cuda.set_device(dev)
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", device_id=dev)
+    t = torch.ones(1 << 20, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    ok = bool((t == float(world) ** 6).all().item())
+    if rank == 0:
+        print("RCCL_SELFTEST " + json.dumps({"ok": ok, "n_ranks": world, "init_and_first_seconds": t1 - t0,
+                                             "allreduce_4MiB_ms": (t2 - t1) / 5 * 1e3}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+def rccl_selftest(n_ranks, limit_s=120.0):
+    """RCCL as a REPORTED pre-/post-flight, not a dependency: N throw-away children (fresh processes -- nothing of this process is
+    re-used or re-exec'ed) each bind GPU r, bring up an RCCL communicator and all_reduce once.  Wall-limited: on expiry every
+    child is killed (own session each, by process group) and the line says so.  -> {"ok", "n_ranks", "seconds", ...| "error"}."""
+    import signal
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    from seq2squiggle_amd.placement import rank_visibility
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                         "OMP_NUM_THREADS", "S2S_PINNED_CPUS") and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_"))}
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    one_gpu = bool(os.environ.get("S2S_BENCH_ONE_GPU"))
+    t0 = time.perf_counter()
+    procs = []
+    try:
+        for r in range(n_ranks):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            if one_gpu:
+                env["S2S_ONE_GPU"] = "1"
+            # (all devices stay visible to a child: RCCL's peer-to-peer transport wants to see its neighbours; the child picks LOCAL_RANK)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rccl-selftest-child"], env=env, cwd=ROOT,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True))
+        deadline = time.perf_counter() + limit_s
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=max(0.1, deadline - time.perf_counter())))
+            except subprocess.TimeoutExpired:
+                raise TimeoutError
+        seconds = time.perf_counter() - t0
+        codes = [p.returncode for p in procs]
+        line = [l for l in outs[0][0].splitlines() if l.startswith("RCCL_SELFTEST ")]
+        if any(codes) or not line:
+            bad = next((i for i, c in enumerate(codes) if c), 0)
+            return {"ok": False, "n_ranks": n_ranks, "seconds": seconds, "exit_codes": codes,
+                    "error": (outs[bad][1] or outs[bad][0]).strip()[-400:]}
+        return dict(json.loads(line[0][len("RCCL_SELFTEST "):]), seconds=seconds)
+    except TimeoutError:
+        return {"ok": False, "n_ranks": n_ranks, "seconds": time.perf_counter() - t0,
+                "error": f"no answer within {limit_s:g} s: the {n_ranks} self-test children were killed"}
+    except Exception as e:
+        return {"ok": False, "n_ranks": n_ranks, "seconds": time.perf_counter() - t0, "error": f"{type(e).__name__}: {e}"}
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.communicate(timeout=30)
+            except Exception:
+                pass
+
+
 WORKLOADS = {"config2": 1000, "config3": 12500}     # reads per GPU: BASELINE.json configs[1] / configs[2] (100,000 reads over 8 GPUs)
 
 
@@ -569,6 +770,46 @@ def launch_ranks(a, argv):
     return p.returncode
 
 
+class Line:
+    """Rank 0's ONE JSON line: built up as the legs finish and written exactly once -- by the end of main(), or by the deadline
+    thread if a secondary leg (anything after the timed region) has not come back in time: the measurement is never lost to a leg."""
+
+    def __init__(self, fd):
+        import threading
+        self.fd, self.out, self.lock, self.done, self.timer = fd, None, threading.Lock(), False, None
+
+    def arm(self, out, seconds):
+        import threading
+        self.out = out
+        self.timer = threading.Timer(seconds, self._expired, args=(seconds,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _expired(self, seconds):
+        with self.lock:
+            if self.done:
+                return
+            self.out["secondary_legs_timed_out"] = {"after_seconds": seconds, "note": "the headline fields were complete; a later leg did not "
+                                                    "return -- the line was written by the deadline thread and the process ended"}
+            self._write()
+        os._exit(0)
+
+    def _write(self):
+        self.done = True
+        sys.stdout.flush()
+        os.write(self.fd, (json.dumps(self.out) + "\n").encode())
+
+    def write(self, out=None):
+        with self.lock:
+            if self.done:
+                return
+            if out is not None:
+                self.out = out
+            if self.timer:
+                self.timer.cancel()
+            self._write()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -581,10 +822,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-launch", action="store_true", help="print the child command --gpus N would start, run nothing")
     ap.add_argument("--launch-selftest", action="store_true",
-                    help="CPU-only check of the launcher: the ranks meet over gloo, rank 0 prints {n_ranks_seen}, no GPU work")
+                    help="CPU-only pass through the multi-rank plumbing of the line (host group, device identities, RCCL self-test, "
+                         "cpu_baseline on rank 0 while the others wait): no GPU work")
+    ap.add_argument("--rccl-selftest-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rccl-selftest-only", type=int, default=0, metavar="N", help="run only the RCCL self-test with N children and print its result")
+    ap.add_argument("--rccl-selftest-limit", type=float, default=float(os.environ.get("S2S_RCCL_SELFTEST_LIMIT", "120")),
+                    help="wall limit of the RCCL self-test in seconds (0 = skip it)")
+    ap.add_argument("--leg-deadline", type=float, default=float(os.environ.get("S2S_BENCH_LEG_DEADLINE", "1500")),
+                    help="seconds after the timed region by which the line is written, whatever the secondary legs are doing")
     ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3", "f16"],
                     help="decoder arithmetic: f32-input MFMA, or split-f16 (3 f16 MFMA products, fp32 accumulate)")
     a = ap.parse_args()
+    if a.rccl_selftest_child:
+        return rccl_selftest_child()
+    if a.rccl_selftest_only:                 # the self-test alone (this process stays off the GPU): proves the bring-up code on whatever is there
+        print(json.dumps({"rccl_selftest": rccl_selftest(a.rccl_selftest_only, a.rccl_selftest_limit)}))
+        return
     n_reads = a.reads if a.reads is not None else WORKLOADS[a.workload]
 
     rank = int(os.environ.get("RANK", "0"))
@@ -594,34 +847,59 @@ def main():
         sys.exit(launch_ranks(a, sys.argv[1:]))            # nothing above this line has initialised the GPU
     if a.gpus != world:
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.launch_selftest:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
-        t = torch.ones(1)
-        dist.all_reduce(t)
-        if rank == 0:
-            print(json.dumps({"launch_selftest": True, "n_gpus": a.gpus, "n_ranks_seen": dist.get_world_size(),
-                              "sum_of_ones": int(t.item())}))
-        dist.destroy_process_group()
-        return
     # stdout carries ONE JSON line: everything else that writes to file descriptor 1 from here on (RCCL's version banner, library
     # chatter) goes to stderr; the line itself is written to the saved descriptor at the end
     sys.stdout.flush()
-    json_fd = os.dup(1)
+    line = Line(os.dup(1))
     os.dup2(2, 1)
-    one_gpu = bool(os.environ.get("S2S_BENCH_ONE_GPU"))          # rehearsal on a 1-GPU box: every rank on cuda:0, barrier over gloo
+    one_gpu = bool(os.environ.get("S2S_BENCH_ONE_GPU"))          # rehearsal on a 1-GPU box: every rank on cuda:0
     if one_gpu:
-        local = 0
-        os.environ["LOCAL_RANK"] = "0"                          # (inference_run picks its device from it)
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST"):      # (the env var exercises the RCCL calls on one GPU)
-        import torch.distributed as dist
-        if one_gpu:
-            dist.init_process_group("gloo")                      # RCCL refuses two ranks on one device
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    red_dev = "cpu" if one_gpu else None
+        os.environ["S2S_ONE_GPU"] = "1"                         # (placement.local_device, inference_run)
+    from seq2squiggle_amd import placement
+    pinned = placement.pin_rank() if world > 1 else None        # before the first GPU call and the first pinned page
+    local = placement.local_device()
+    host = HostGroup(world)                                      # gloo on host tensors: the bench needs no RCCL (the path has no exchange)
+    selftest_mode = a.launch_selftest
+    if not selftest_mode:
+        torch.cuda.set_device(local)
+    devices = host.gather(dict(device_identity(None if selftest_mode else local) or {}, rank=rank, pid=os.getpid(),
+                               cpus=(pinned or {}).get("cpus"), numa_node=(pinned or {}).get("numa_node")))
+    distinct = devices_distinct(devices)
+
+    def multi_rank_fields(out):
+        out["barrier_backend"] = host.backend
+        out["per_rank_device"] = devices
+        out["devices_distinct"] = distinct
+
+    def rccl_leg():
+        """Rank 0 runs the self-test's children while the others wait at the host barrier."""
+        res = None
+        if rank == 0 and world > 1 and a.rccl_selftest_limit > 0:
+            res = rccl_selftest(world, a.rccl_selftest_limit)
+        host.barrier()
+        return res
+
+    if selftest_mode:
+        # the multi-rank plumbing of the line without a GPU: the same host group, gather, self-test and rank-0-only leg as the real run
+        t0 = time.perf_counter()
+        host.barrier()
+        el = host.max(time.perf_counter() - t0)
+        ones = host.gather(1)
+        out = {"launch_selftest": True, "n_gpus": a.gpus, "n_ranks_seen": host.size(), "sum_of_ones": int(sum(ones)), "barrier_seconds": el}
+        multi_rank_fields(out)
+        if rank == 0:
+            line.arm(out, a.leg_deadline)
+        res = rccl_leg()
+        if rank == 0:
+            out["rccl_selftest"] = res
+            if not a.no_cpu_baseline:
+                sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
+                out["cpu_baseline"] = cpu_baseline(sd, cfg, None, seconds_target=0.2, sample_chunks=16)
+        host.barrier()
+        if rank == 0:
+            line.write()
+        host.close()
+        return
 
     sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
     eng = S.Engine(sd, cfg, device=local, mode=a.mode)
@@ -643,30 +921,21 @@ def main():
     torch.cuda.synchronize()
     eng.stats()                                            # reset: the counters below are those of the timed launches
     eng.set_profiling(True)
-    if dist:
-        dist.barrier()
+    host.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
     own = time.perf_counter() - t0                         # this rank's own time, before waiting for the others
-    if dist:
-        dist.barrier()
+    host.barrier()
     el = time.perf_counter() - t0
     eng.set_profiling(False)
     dec_ms, dec_launches, dec_chunks = eng.kernel_ms()
     live = eng.stats()
-    ranks_seen, per_rank = 1, [B * a.steps / own]
-    if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=red_dev or dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-        ranks_seen = dist.get_world_size()
-        mine = torch.tensor([B * a.steps / own], dtype=torch.float64, device=red_dev or dev)
-        allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
-        dist.all_gather(allr, mine)
-        per_rank = [float(x.item()) for x in allr]
+    el = host.max(el)
+    ranks_seen = host.size()
+    per_rank = [float(x) for x in host.gather(B * a.steps / own)]
     emitted = int((sig != 0).sum().item())
     # the reference's default batch (1024 chunks per call), reported for transparency only; skipped with
     # --no-cpu-baseline so that a rocprofv3 --stats of that command averages the bench launches alone
@@ -682,13 +951,7 @@ def main():
         torch.cuda.synchronize()
         small_rate = reps * small / (time.perf_counter() - t1)
 
-    sharded, sharded_failed = None, False
-    if dist and (world > 1 or os.environ.get("S2S_BENCH_FORCE_DIST")) and not a.no_cpu_baseline:      # (the env var: the leg's RCCL calls on one GPU)
-        try:
-            sharded = end_to_end_sharded(a.mode, dist, rank, world, dev)
-        except Exception as e:                                 # (a lost rank, a gloo timeout): the headline line still goes out
-            sharded = {"error": [f"rank {rank}: {type(e).__name__}: {e}"]}
-            sharded_failed = True
+    out = None
     if rank == 0:
         chunks_total = B * a.steps * world
         chunks_s = chunks_total / el
@@ -715,6 +978,7 @@ def main():
                 "flop_per_chunk": FLOP_PER_CHUNK_DOMINANT,
                 "avg_launch_ms": dec_ms / dec_launches if dec_launches else None,
                 "launches": dec_launches, "chunks_per_launch": cpl}
+        roof.update(pmc.get("extra", {}))
         if a.mode == "f16x3" and tflops:
             # secondary readings: every algorithmic product costs three f16 MFMA products in this arithmetic, and the
             # native exact-f32 alternative is the f32-input MFMA
@@ -740,38 +1004,75 @@ def main():
             "chunks_per_sec_at_reference_batch_1024": small_rate,
             "roofline": roof,
         }
-        if sharded:
+        multi_rank_fields(out)
+        if one_gpu:
+            out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 -- NOT a scaling measurement"
+        elif world > 1 and distinct is False:
+            out["invalid"] = "two ranks reported the same GPU: this is not an N-GPU measurement"
+            print("bench.py: " + out["invalid"], file=sys.stderr)
+        # from here on the line exists: whatever the secondary legs do, it is written by the deadline at the latest
+        line.arm(out, a.leg_deadline)
+
+    def leg(name, fn, *args):                    # a secondary leg that fails (a full disk, ...) must not cost the line
+        try:
+            out[name] = fn(*args)
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+
+    sharded_failed = False
+    if host.dist and not a.no_cpu_baseline:
+        sharded = None
+        try:
+            sharded = end_to_end_sharded(a.mode, host.dist, rank, world, dev)
+        except Exception as e:                                 # (a lost rank, a gloo timeout): the headline line still goes out
+            sharded = {"error": [f"rank {rank}: {type(e).__name__}: {e}"]}
+            sharded_failed = True
+        if rank == 0 and sharded:
             out["end_to_end_sharded"] = sharded
+            chunks_s = out["chunks_per_sec"]
             if "chunks_per_sec" in sharded:
-                out["end_to_end_sharded"]["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
+                sharded["of_resident_rate"] = sharded["chunks_per_sec"] / chunks_s
                 for part in (sharded.get("with_merge", {}), sharded.get("one_command", {}), sharded.get("one_command", {}).get("join_live", {})):
                     if "chunks_per_sec" in part:                    # ... with the merge into ONE file, and as the one command with its launch
                         part["of_resident_rate"] = part["chunks_per_sec"] / chunks_s
-        if one_gpu:
-            out["one_gpu_rehearsal"] = "S2S_BENCH_ONE_GPU: all ranks share cuda:0 (gloo barrier) -- NOT a scaling measurement"
-        if world == 1 and not a.no_cpu_baseline:
-            def leg(name, fn, *args):                    # a secondary leg that fails (a full disk, ...) must not cost the line
-                try:
-                    out[name] = fn(*args)
-                except Exception as e:
-                    out[name] = {"error": f"{type(e).__name__}: {e}"}
-                    print(f"bench.py: {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+    if sharded_failed:                                         # the groups are in an unknown state: no further collective
+        if rank == 0:
+            line.write()
+        os._exit(0)
+    if world > 1:
+        # RCCL, reported: after the measurement, in processes of their own (rank 0 starts them, the others wait at the host barrier)
+        try:
+            res = rccl_leg()
+        except Exception as e:
+            res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            out["rccl_selftest"] = res
+    if rank == 0 and not a.no_cpu_baseline:
+        if world == 1:
             leg("end_to_end", end_to_end, a.mode)
-            leg("cpu_baseline", cpu_baseline, sd, cfg, eng)
-            if "value" in out["cpu_baseline"]:
-                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        leg("cpu_baseline", cpu_baseline, sd, cfg, eng)         # (N > 1: rank 0 alone, the others wait at the host barrier below)
+        if "value" in out["cpu_baseline"]:
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu_note"] = "whole job over ONE host's CPU baseline" if world > 1 else None
+        if world == 1:
             leg("config4_k6", config4_k6_leg, a.mode, dev, a.steps)
             if a.mode != "f32":
                 leg("weight_sensitivity", weight_sensitivity_leg, a.mode, bases_d, nv_d, sig, dur, params, max(2, min(a.steps, 5)))
             if a.mode == "f16x3":
                 leg("reduced_precision", reduced_precision_leg, sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if sharded_failed:
-        os._exit(0)                                            # the groups are in an unknown state: no collective shutdown
+    try:
+        host.barrier()
+    except Exception as e:                                     # (rank 0 took longer than the group's timeout: the others just leave)
+        print(f"bench.py: rank {rank}: final barrier: {type(e).__name__}: {e}", file=sys.stderr)
+        if rank != 0:
+            os._exit(0)
+    if rank == 0:
+        line.write()
     eng.close()
-    if dist:
-        dist.destroy_process_group()
+    host.close()
+    if rank == 0 and out.get("invalid"):
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -17,6 +17,20 @@ def deps():
 LIB = os.path.join(HERE, "lib", "libs2s_hip.so")
 
 
+def source_hash() -> str:
+    """sha256 over every file the library is compiled from (deps(): path relative to the repository, NUL, content): what ties a
+    committed profile (profiles/rNN/pmc_summary.json: `_meta.csrc_sha256`) to the kernel source it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(HERE)
+    for d in deps():
+        h.update(os.path.relpath(d, root).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

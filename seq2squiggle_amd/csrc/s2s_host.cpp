@@ -1011,6 +1011,11 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
         mapped = map_spans(dsts);
         if (!mapped) unmap_spans(dsts);
     }
+    // every piece's destination mapping is looked up HERE, on one thread: the workers only read the vector (std::map::operator[] is
+    // a non-const member, and concurrent calls of it are a data race on paper even when every key exists)
+    std::vector<const Span*> span_of(pieces.size(), nullptr);
+    if (mapped)
+        for (size_t i = 0; i < pieces.size(); ++i) span_of[i] = &dsts.find(pieces[i].dst)->second;
     std::atomic<size_t> next{0};
     std::atomic<int64_t> err{0};
     auto work = [&] {
@@ -1021,7 +1026,7 @@ extern "C" int64_t s2s_copy_ranges(int32_t n, const int32_t* src_fd, const int64
             if (i >= pieces.size() || err.load()) return;
             const Piece& p = pieces[i];
             if (mapped) {
-                const Span& b = dsts[p.dst];
+                const Span& b = *span_of[i];
                 uint8_t* to = b.base + (p.d_o - b.lo);
 #ifdef MADV_POPULATE_WRITE
                 const uintptr_t lo = (uintptr_t)to & ~(uintptr_t)4095, hi = ((uintptr_t)to + (uintptr_t)p.len + 4095) & ~(uintptr_t)4095;

@@ -18,6 +18,7 @@ there, and the one writer does 7-10 GB/s) s2s_copy_ranges takes copy_file_range 
 `consume=True` deletes every other shard as soon as its bytes are in the output, on a helper thread beside the copy of the
 next one (freeing 6 GB of tmpfs pages takes 0.5 s, and the pages go straight back to the copy: the peak is the output + one shard,
 not twice the output)."""
+import logging
 import os
 import struct
 import time
@@ -25,6 +26,8 @@ from concurrent.futures import ThreadPoolExecutor
 from typing import List, Sequence, Tuple
 
 import numpy as np
+
+logger = logging.getLogger("seq2squiggle")
 
 BLOW5_EOF = b"5WOLB"
 
@@ -290,6 +293,31 @@ class LiveJoin:
         self.blocks, self.placed = [], [[] for _ in range(self.n)]      # POD5
         self.head_len = None
         self._punch = _Puncher() if punch else None
+        self._unpunched = []                     # copied ranges whose pages wait for the last shard's header check
+        self.punched = 0                         # bytes of rank files already given back: from then on the partial output is the only copy
+        self._pa = None
+        if self.kind == "pod5":                  # everything the finish needs is loaded BEFORE the first byte is consumed
+            from . import pod5_io as P
+            self._pa = P._pa()
+
+    @staticmethod
+    def _blow5_header_lines(text: bytes):
+        return [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]
+
+    def _check_against_first(self, r: int) -> None:
+        """A shard that does not belong to shard 0's run (another profile, compression, schema) is refused when its header is first
+        seen -- before anything of it is copied or punched -- not when the ranks are done and their files are hollow."""
+        if r == 0 or self.headers[0] is None:
+            return
+        if self.kind == "blow5":
+            head, text = self.headers[r]
+            if head != self.headers[0][0] or self._blow5_header_lines(text) != self._blow5_header_lines(self.headers[0][1]):
+                raise ValueError(f"{self.paths[r]}: header differs from {self.paths[0]} (another profile, compression or run?)")
+        else:
+            pa = self._pa
+            schemas = [pa.ipc.read_schema(pa.py_buffer(self.headers[i][32:])).remove_metadata() for i in (0, r)]
+            if schemas[0] != schemas[1]:
+                raise ValueError(f"{self.paths[r]}: signal table schema differs from {self.paths[0]} (VBZ and uncompressed shards do not mix)")
 
     # ---- shard headers
     def _open(self, r: int) -> bool:
@@ -327,6 +355,11 @@ class LiveJoin:
                 return False
             self.headers[r] = os.pread(fd, 40 + mlen, 0)               # signature, marker, Arrow magic, schema message (no body)
             self.pos[r] = 40 + mlen
+        try:
+            self._check_against_first(r)
+        except BaseException:
+            self.pos[r] = None
+            raise
         return True
 
     def _start_output(self) -> bool:
@@ -411,7 +444,14 @@ class LiveJoin:
                     self.blocks.append((at - 24, meta_len, 0, body))       # (Arrow block offsets count from the embedded file's start)
                     at += meta_len + body
             if self._punch is not None:
-                self._punch.punch(fd, begin, end)
+                # nothing is given back before EVERY shard's header has been seen and held against shard 0's: until then the rank
+                # files stay whole, and a shard that does not belong here fails the join with nothing lost
+                self._unpunched.append((fd, begin, end))
+                if all(p_ is not None for p_ in self.pos):
+                    for fd_, lo, hi in self._unpunched:
+                        self._punch.punch(fd_, lo, hi)
+                        self.punched += hi - lo
+                    self._unpunched = []
             self.out_pos += end - begin
             self.pos[r] = end
             self.units += got
@@ -444,40 +484,63 @@ class LiveJoin:
         if self._punch is not None:
             self._punch.finish()
         if self.kind == "blow5":
-            same = lambda text: [l for l in text.decode().splitlines() if not l.startswith("@exp_start_time")]
-            for p_, (head, text) in zip(self.paths[1:], self.headers[1:]):
-                if head != self.headers[0][0] or same(text) != same(self.headers[0][1]):
-                    raise ValueError(f"{p_}: header differs from {self.paths[0]} (another profile, compression or run?)")
+            for r in range(1, self.n):                 # (checked when each header was first seen; once more costs nothing)
+                self._check_against_first(r)
             os.pwrite(self.out_fd, BLOW5_EOF, self.out_pos)
             os.ftruncate(self.out_fd, self.out_pos + len(BLOW5_EOF))
             n = self.units
-            for fd in self.fds:
-                os.close(fd)
-            os.close(self.out_fd)
+            self._close_shards()
+            self._close_out()
             if consume:
                 for p_ in self.paths:
                     os.remove(p_)
         else:
             from . import pod5_io as P
-            for fd in self.fds:
-                os.close(fd)
+            self._close_shards()                       # (merge_pod5 opens its own descriptors: ours must not be closed again later)
             blocks = np.array(self.blocks, dtype=P._BLOCK) if self.blocks else np.zeros(0, P._BLOCK)
             n = P.merge_pod5(self.paths, self.out, threads=self.threads, consume=consume,
                              _live={"fd": self.out_fd, "blocks": blocks, "placed": self.placed, "msg_base": self.out_pos - 24,
                                     "head_len": self.head_len})
-            os.close(self.out_fd)
+            self._close_out()
         stats = {"live_bytes": live_bytes, "bytes": os.path.getsize(self.out), "finish_seconds": time.perf_counter() - t0,
                  "copy_seconds": self.copy_seconds, "units_live": self.units, "threads": self.threads,
                  "engine": "map" if merge_engine() else "fd", "order": f"round robin, {self.q} {'records' if self.kind == 'blow5' else 'signal batches'} per rank and turn"}
         return n, stats
 
-    def abort(self) -> None:
-        for fd in [f for f in self.fds if f is not None] + ([self.out_fd] if self.out_fd is not None else []):
+    def _close_shards(self) -> None:
+        for r, fd in enumerate(self.fds):
+            if fd is not None:
+                self.fds[r] = None                     # (ours no longer: the number may be handed out again at once)
+                try:
+                    os.close(fd)
+                except OSError:
+                    pass
+
+    def _close_out(self) -> None:
+        fd, self.out_fd = self.out_fd, None
+        if fd is not None:
             try:
                 os.close(fd)
             except OSError:
                 pass
-        if os.path.exists(self.out):
+
+    def abort(self) -> None:
+        """Gives up.  While nothing has been punched out of the rank files they still hold everything and the partial output goes;
+        once pages have been given back the partial output is the ONLY copy of those records: it stays, and the log says where."""
+        self._close_shards()
+        self._close_out()
+        if self._punch is not None:
+            try:
+                self._punch.finish()
+            except Exception:
+                pass
+        if not os.path.exists(self.out):
+            return
+        if self.punched:
+            logger.error(f"live join failed after {self.punched} bytes of the rank files had been released (they read as zeros there now): "
+                         f"the records copied so far are kept in {self.out} (incomplete: no end marker / tables); the rank files "
+                         f"{', '.join(self.paths)} keep what had not been copied yet. Re-run with --join after to be safe.")
+        else:
             os.remove(self.out)
 
 

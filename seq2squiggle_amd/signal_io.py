@@ -81,6 +81,16 @@ def _skip_record_draws(n_reads: int) -> None:
         np.random.normal(size=2 * (n_reads % 65536))
 
 
+_WARNED = set()
+
+
+def warn_once(key: str, message: str) -> None:
+    """A standing caveat (a container layout nobody has opened with the real library) is said once per process, not once per writer."""
+    if key not in _WARNED:
+        _WARNED.add(key)
+        logger.warning(message)
+
+
 def cpu_share() -> int:
     """Worker threads this process may keep busy: the cores it is allowed on, capped by the container's CPU quota (cgroup
     cpu.max -- more runnable threads than the quota buys get the whole group throttled for the rest of the scheduler period,
@@ -144,7 +154,7 @@ class BLOW5Writer:
         self._out = None                      # packed records of the batch being written
         self._warned_fallback = False
         if self.signal_compression == "svb-zd":
-            logger.warning("BLOW5 signal compression svb-zd is EXPERIMENTAL here: the codec is pinned by known-answer vectors, "
+            warn_once("svb-zd", "BLOW5 signal compression svb-zd is EXPERIMENTAL here: the codec is pinned by known-answer vectors, "
                            "but how slow5lib frames the blob inside a record could not be checked against the library; files "
                            "written this way may not open in slow5tools. The default (zlib records, raw int16 signal) is safe.")
 
@@ -577,8 +587,8 @@ class POD5Writer:
             logger.warning("POD5 was not exported. No signals were found")
             raise ValueError("POD5 was not exported. No signals were found")
         from . import pod5_io
-        logger.warning("POD5 output comes from seq2squiggle_amd's own container writer (unvalidated against ONT's pod5 "
-                       "library, which this image lacks).")
+        warn_once("pod5", "POD5 output comes from seq2squiggle_amd's own container writer (unvalidated against ONT's pod5 "
+                  "library, which this image lacks).")
         pod5_io.write_pod5(self.filename, self.records())
 
     # ---- streaming path (inference.run_streaming): samples already int16 on the GPU, reads arrive in super-batches and
@@ -664,9 +674,9 @@ class POD5Writer:
         self._zstd_rows(recs)
         if self._stream is None:
             from . import pod5_io
-            logger.warning("POD5 output comes from seq2squiggle_amd's own container writer: record content and the VBZ codec "
-                           "are pinned against the reference / known-answer vectors, but no file has been opened with ONT's "
-                           "pod5 library yet (absent from this image). Prefer .blow5 where the consumer allows it.")
+            warn_once("pod5", "POD5 output comes from seq2squiggle_amd's own container writer: record content and the VBZ codec "
+                      "are pinned against the reference / known-answer vectors, but no file has been opened with ONT's "
+                      "pod5 library yet (absent from this image). Prefer .blow5 where the consumer allows it.")
             self._stream = pod5_io.Pod5FileWriter(self.filename)
         self._stream.add_reads(recs)
 

@@ -710,8 +710,11 @@ def _variant(sd, kind):
 
 
 def _parity_both_paths(sd, cfg, reads, label, want_mixed=None):
-    """reads -> chunks -> fast and exact path against the fp32 and fp64 oracle (dwell indices and zero pattern exact, signal within
-    the parity bound or within 5 x the fp32 oracle's own distance to fp64 where near-one-hot rows amplify rounding).
+    """reads -> chunks -> fast and exact path against the fp32 and fp64 oracle: dwell indices exact; the signal within the parity
+    bound (MAE < 1e-4 pA, max < 2e-3 pA against the fp32 oracle -- no alternative branch: every variant has measured 4-6e-5 / 2-4e-4
+    since round 5, profiles/r05/redo_and_mixed_regime_tests.txt) AND no further from the fp64 evaluation than 5 x the fp32 oracle
+    itself is; the zero pattern equal except where a ReLU output sits within the parity bound of zero (a sample may be 0 on one side
+    and < 2e-3 pA on the other -- counted, printed, and held below 0.05 % of the samples).
     -> (calibration redo rate, redo rate of this input on the fast path, the CPU model's)."""
     from oracle import redo_model as R
     k = cfg["seq_kmer"]
@@ -740,16 +743,20 @@ def _parity_both_paths(sd, cfg, reads, label, want_mixed=None):
         assert np.array_equal(out["dur"].cpu().numpy(), ref["dur"].numpy()), (label, path)
         same = (y == 0) == (r == 0)
         assert same.mean() > 0.9995, (label, path, same.mean())
+        flipped = int((~same).sum())
+        if flipped:                                    # a sample that is zero on one side only is within the bound of zero on the other
+            assert np.abs(y - r)[~same].max() < MAX_TOL, (label, path, flipped, np.abs(y - r)[~same].max())
         mae, mx = np.abs(y - r)[same].mean(), np.abs(y - r)[same].max()
         err_gpu = np.abs(y - t)[same & agree64].mean()
-        assert (mae < MAE_TOL and mx < MAX_TOL) or err_gpu < 5 * err_ref, (label, path, mae, mx, err_gpu, err_ref)
+        assert mae < MAE_TOL and mx < MAX_TOL, (label, path, mae, mx)
+        assert err_gpu < 5 * err_ref, (label, path, err_gpu, err_ref)
         if path == "fast":
             live = st["redo_rate"]
             if want_mixed:
                 assert 0 < st["softmax_redone"] < 0.5 * st["softmax_runs"], (label, st)      # some heads of a launch redone, their partners not
         else:
             assert st["softmax_redone"] == 0 and st["chunks_on_exact_path"] == B
-        print(f"MIXED {label} {path}: {B} chunks, redo {st['redo_rate']:.4f} (calibration {calib:.4f}), MAE {mae:.2e} max {mx:.2e} "
+        print(f"MIXED {label} {path}: {B} chunks, redo {st['redo_rate']:.4f} (calibration {calib:.4f}), zero-pattern flips {flipped} of {same.size}, MAE {mae:.2e} max {mx:.2e} "
               f"vs fp64 {err_gpu:.2e} (fp32 oracle vs fp64 {err_ref:.2e})")
     eng.close()
     model = R.predicted_redo_rate(sd, cfg, codes, gi)

@@ -1051,6 +1051,69 @@ def test_live_join_refuses_a_rank_file_that_does_not_end(tmp_path):
         M.LiveJoin(shards, str(tmp_path / "x.slow5"))
 
 
+def _allocated(path):
+    return os.stat(path).st_blocks
+
+
+@pytest.mark.parametrize("ext", ["blow5", "pod5"])
+def test_live_join_checks_every_header_before_it_gives_a_page_back(tmp_path, ext):
+    """the live join frees the pages of what it has copied.  Two shards that do not belong together -- another
+    profile in the BLOW5 header, a VBZ and an uncompressed POD5 signal table -- used to be noticed in finish(), when the rank files
+    were hollow and abort() had deleted the partial output: everything gone.  Now every shard's header is held against shard 0's
+    when it is first seen and nothing is punched before all of them have passed: the join fails with the rank files whole."""
+    from seq2squiggle_amd import merge as M
+    rng = np.random.default_rng(3)
+    lens = list(rng.integers(3000, 9000, 700))
+    if ext == "blow5":
+        shards = _write_shards(tmp_path, ext, lens, ((0, 350), (350, 700)), rng, tag="h")
+        raw = open(shards[1], "rb").read()
+        assert b"dna-r10-prom" in raw[:4096] or b"sample_frequency" in raw[:4096]
+        other = raw.replace(b"@asic_id", b"@asic_ix", 1) if b"@asic_id" in raw[:4096] else raw.replace(b"sample_frequency", b"sample_frequencx", 1)
+        assert other != raw and len(other) == len(raw)
+        open(shards[1], "wb").write(other)
+        match = "header differs"
+    else:
+        a = _write_shards(tmp_path, ext, lens[:350], ((0, 350),), rng, signal_compression="vbz", tag="h0")
+        b = _write_shards(tmp_path, ext, lens[350:], ((0, 350),), rng, signal_compression="none", tag="h1")
+        shards = [str(tmp_path / "h.rank0.pod5"), str(tmp_path / "h.rank1.pod5")]
+        os.rename(a[0], shards[0])
+        os.rename(b[0], shards[1])
+        match = "schema differs"
+    before = [open(p_, "rb").read() for p_ in shards]
+    blocks = [_allocated(p_) for p_ in shards]
+    out = str(tmp_path / f"h.live.{ext}")
+    live = M.LiveJoin(shards, out, threads=1, punch=True)
+    with pytest.raises(ValueError, match=match):
+        live.finish()
+    live.abort()
+    assert live.punched == 0 and not os.path.exists(out)
+    assert [open(p_, "rb").read() for p_ in shards] == before           # nothing was hollowed out
+    assert [_allocated(p_) for p_ in shards] == blocks
+
+
+def test_live_join_keeps_the_partial_output_once_pages_are_gone(tmp_path, caplog):
+    """... and if the join fails AFTER pages have been given back (a torn last record, a full disk), the partial output is the only
+    copy of those records: abort() keeps it and the log says where, instead of deleting it."""
+    import logging
+    from seq2squiggle_amd import merge as M
+    rng = np.random.default_rng(4)
+    lens = list(rng.integers(3000, 9000, 1200))
+    shards = _write_shards(tmp_path, "blow5", lens, ((0, 600), (600, 1200)), rng, tag="k")
+    whole = open(shards[1], "rb").read()
+    open(shards[1], "wb").write(whole[:-9])                          # rank 1's file stops inside its last record
+    out = str(tmp_path / "k.live.blow5")
+    live = M.LiveJoin(shards, out, threads=1, punch=True)
+    with caplog.at_level(logging.ERROR, logger="seq2squiggle"):
+        with pytest.raises(ValueError, match="end-of-file marker"):
+            live.finish()
+        assert live.punched > 0
+        live.abort()
+    assert os.path.exists(out) and os.path.getsize(out) > 1 << 20
+    assert out in caplog.text and "kept" in caplog.text
+    assert live.fds == [None, None] and live.out_fd is None
+    live.abort()                                                      # (idempotent: closes nothing twice)
+
+
 def test_cli_rank_file_names_are_those_of_the_ranks():
     """`predict --gpus N --join live` names the rank files itself before it starts the ranks (so that nothing heavy is imported in front
     of their start): the names must be parallel.rank_output_path's, which the ranks use."""

@@ -14,7 +14,16 @@ def _is_test_instance(name):
     return len(args) > 1 and args[1] == "true"
 
 
+import subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
+meta = {"csrc_sha256": None, "git_commit": None, "by_mode": {}}
+try:
+    meta["git_commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    meta["git_dirty_csrc"] = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "seq2squiggle_amd/csrc", "include"],
+                                                 capture_output=True, text=True).stdout.strip())
+except OSError:
+    pass
 for arg in sys.argv[1:]:
     mode, d = arg.split("=", 1)
     d, _, chunks = d.partition(":")
@@ -52,4 +61,11 @@ for arg in sys.argv[1:]:
                     k["_effective_clock_ghz"] = k["GRBM_GUI_ACTIVE"] / 8 / k["_duration_ns"][tag]
                     break
     out[mode] = per
+    try:                                  # tools/pmc_run.sh wrote the hash of the sources the passes ran on
+        meta["by_mode"][mode] = open(os.path.join(d, "csrc_sha256.txt")).read().strip()
+    except OSError:
+        meta["by_mode"][mode] = None
+hashes = {h for h in meta["by_mode"].values() if h}
+meta["csrc_sha256"] = hashes.pop() if len(hashes) == 1 else None          # one hash for all modes, or none
+out["_meta"] = meta
 json.dump(out, sys.stdout, indent=1)
