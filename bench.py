@@ -364,13 +364,23 @@ def weight_sensitivity_leg(mode, bases_d, nv_d, sig, dur, params, steps):
             "min_chunks_per_sec": min(rates), "max_chunks_per_sec": max(rates)}
 
 
-def cpu_baseline(sd, cfg, eng, seconds_target=12.0, sample_chunks=1024):
+def cpu_baseline(sd, cfg, eng, seconds_target=12.0, sample_chunks=1024, whole_node=None):
     """Oracle (CPU port of the reference op sequence, torch fp32 'highest') on the host cores, plus a live parity
     check of the engine against it on the first 256 chunks of the sample (injected variates)."""
     from oracle import s2s_oracle as O
     from seq2squiggle_amd.signal_io import cpu_share
     torch.set_float32_matmul_precision("highest")
-    torch.set_num_threads(cpu_share())      # the cores this container may actually keep busy (cgroup quota), not the host's count
+    threads = cpu_share()                   # the cores this container may actually keep busy (cgroup quota), not the host's count
+    if whole_node:
+        # N > 1: rank 0 runs this leg alone while the other ranks wait at the host barrier -- it may use the node's whole CPU share,
+        # not its own 1 / N of it: the mask placement.pin_rank narrowed is widened again for the leg's threads
+        try:
+            from seq2squiggle_amd.placement import parse_cpulist
+            os.sched_setaffinity(0, parse_cpulist(whole_node))
+        except (OSError, ValueError, AttributeError):
+            pass
+        threads *= max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    torch.set_num_threads(threads)
     reads = make_reads(4, 99)
     codes = np.concatenate([O.encode_read(r, cfg["seq_kmer"]) for r in reads], 0)[:sample_chunks]
     p = O.PredictParams()
@@ -894,7 +904,7 @@ def main():
             out["rccl_selftest"] = res
             if not a.no_cpu_baseline:
                 sd, cfg = S.load_checkpoint(os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"))
-                out["cpu_baseline"] = cpu_baseline(sd, cfg, None, seconds_target=0.2, sample_chunks=16)
+                out["cpu_baseline"] = cpu_baseline(sd, cfg, None, seconds_target=0.2, sample_chunks=16, whole_node=(pinned or {}).get("allowed"))
         host.barrier()
         if rank == 0:
             line.write()
@@ -1051,7 +1061,8 @@ def main():
     if rank == 0 and not a.no_cpu_baseline:
         if world == 1:
             leg("end_to_end", end_to_end, a.mode)
-        leg("cpu_baseline", cpu_baseline, sd, cfg, eng)         # (N > 1: rank 0 alone, the others wait at the host barrier below)
+        # (N > 1: rank 0 alone, on the node's whole CPU share, while the others wait at the host barrier below)
+        leg("cpu_baseline", lambda: cpu_baseline(sd, cfg, eng, whole_node=(pinned or {}).get("allowed") if world > 1 else None))
         if "value" in out["cpu_baseline"]:
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["gpu_over_cpu_note"] = "whole job over ONE host's CPU baseline" if world > 1 else None

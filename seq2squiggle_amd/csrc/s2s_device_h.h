@@ -68,6 +68,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef S2S_ONLINE_HI_MAX
 #define S2S_ONLINE_HI_MAX 1     // softmax_pv32_online takes a pass's row maxima from the FIRST score MFMA alone (0: from the full score, A/B)
 #endif
+#ifndef S2S_INT_SHIFT
+#define S2S_INT_SHIFT 1         // softmax_pv32_online rounds its shift UP to an integer: one f16 half carries it -- no lo half, no re-encoding (round 6:
+                                // 201.6 k -> 200.25 k cycles per chunk at the same clock, + 0.8 % chunks/s, MAE unchanged; 0: the two-half shift, A/B)
+#endif
+#ifndef S2S_MFMA_SPLIT
+#define S2S_MFMA_SPLIT 0        // 1: the lo half of P comes from the matrix pipe (pv_split_mfma below) instead of v_fma_mix.  Round 6, same-box A/B
+                                // (profiles/r06/ab_mfma_split.txt): 190.2 k -> 180.5 k cycles per chunk (exact: 201.6 k -> 191.2 k), MAE unchanged -- and the
+                                // clock under the kernel falls from 2.29 to 2.18 GHz: the same chunks per second to 0.1 %.  The kernel is ENERGY bound.
+#endif
 #ifndef S2S_ONE_ZEROS_ROW
 #define S2S_ONE_ZEROS_ROW 0     // 1: round 2's single zeros row (2-way LDS bank conflict on every V read; kept for the counter A/B)
 #endif
@@ -380,6 +389,54 @@ __device__ __forceinline__ float sum_h(float v) {
     auto t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
+// P = hi + lo WITHOUT the vector ALU's v_fma_mix (8 issue cycles per score, the largest single item of the attention loop beside the
+// exponential itself): hi = f16(P) is one v_cvt_pk per two scores; lo = P - hi is computed by the MATRIX pipe as
+//     D = C + A . B   with C = the f32 tile of P (the exponentials, in place), B = the hi operand the P.V product takes anyway,
+//                     A = a constant 32 x 16 selection matrix holding one -1 per row,
+// once per 16-key step (two MFMAs per 32-key tile): every element of D receives exactly one non-zero product, -hi of its own
+// position, so D = P - hi to the accumulator's precision (hi is P rounded to 11 bits: the difference is exact in fp32), and a second
+// v_cvt_pk per two scores turns it into the lo operand.  Vector issue per score: 7.9 (v_exp_f32) + 2 x 2.06 (v_cvt_pk / 2) = 12.0
+// cycles against 18.0 (profiles/r02/valu_cost_probe.txt); the matrix pipe takes 2 more 32x32x16 products per tile (6 -> 8).
+// Which element of A: the B operand of step st carries, in k-slot 8 h' + j of column n, the register 8 st + j of lane (n, h'),
+// i.e. tile row (j & 3) + 8 (j >> 2) + 4 h' + 16 st; lane (row, h') of the A operand holds k-slots 8 h' .. 8 h' + 7 of that row: the
+// -1 sits in the lane whose half h' equals bit 2 of the row, at j = (row & 3) + 4 ((row >> 3) & 1), in the step st = row >> 4.
+struct SelA { h8 a[2]; };
+__device__ __forceinline__ SelA split_selectors(const int h) {
+    const int row = threadIdx.x & 31, rho = row & 15;
+    const int j = (rho & 3) + 4 * (rho >> 3);
+    const unsigned w = (((rho >> 2) & 1) == h) ? ((j & 1) ? 0xBC000000u : 0x0000BC00u) : 0u;      // f16 -1.0 in the low / high half
+    uv4 sel;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sel[d] = (j >> 1) == d ? w : 0u;
+    const uv4 z = {0u, 0u, 0u, 0u};
+    SelA o;
+    o.a[0] = __builtin_bit_cast(h8, row < 16 ? sel : z);
+    o.a[1] = __builtin_bit_cast(h8, row < 16 ? z : sel);
+    return o;
+}
+// one 32-key tile: sc = the shifted scores (f32, C layout) -> O += [V_hi; V_lo; 1] . exp2(sc), hi and lo halves
+template <bool LO>
+__device__ __forceinline__ void pv_split_mfma(f32x16 sc, const h8 (&va)[2], const SelA& sel, f32x16& O) {
+    unsigned hw[8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) hw[p] = __builtin_bit_cast(unsigned, (h2v{(_Float16)sc[2 * p], (_Float16)sc[2 * p + 1]}));
+    const h8 hb0 = __builtin_bit_cast(h8, (uv4{hw[0], hw[1], hw[2], hw[3]})), hb1 = __builtin_bit_cast(h8, (uv4{hw[4], hw[5], hw[6], hw[7]}));
+    if (LO) {
+        sc = MFMAW(sel.a[1], hb1, MFMAW(sel.a[0], hb0, sc));          // P - hi, from the matrix pipe
+        unsigned lw[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) lw[p] = __builtin_bit_cast(unsigned, (h2v{(_Float16)sc[2 * p], (_Float16)sc[2 * p + 1]}));
+        O = MFMAW(va[0], hb0, O);
+        O = MFMAW(va[0], __builtin_bit_cast(h8, (uv4{lw[0], lw[1], lw[2], lw[3]})), O);
+        O = MFMAW(va[1], hb1, O);
+        O = MFMAW(va[1], __builtin_bit_cast(h8, (uv4{lw[4], lw[5], lw[6], lw[7]})), O);
+    } else {
+        O = MFMAW(va[0], hb0, O);
+        O = MFMAW(va[1], hb1, O);
+    }
+}
 template <int TV, bool SAFE, bool LO, bool NATURAL = false>
 __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, const _Float16* __restrict__ kp2, const _Float16* __restrict__ vp,
                                              const h8 qb1, const h8 qb2, const float one, const int h, f32x16& O,
@@ -406,6 +463,9 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
     };
     f32x16 negm = zero16;
     h8 qb2m = qb2;
+#if S2S_MFMA_SPLIT
+    [[maybe_unused]] const SelA sel = split_selectors(h);
+#endif
     if constexpr (!SAFE) {
         // fast path: the shift is pass 0's column max (+ head-room), later passes compute no max at all.  Two tiles (64 keys) per
         // pass, as straight-line code.  (Measured: issuing tile t+1's score MFMAs ahead of tile t's exponentials by hand -- no
@@ -496,6 +556,10 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
                 }
             }
 #endif
+#if S2S_MFMA_SPLIT
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pv_split_mfma<LO>(sc[i], va[i], sel, O);
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -506,6 +570,7 @@ __device__ __forceinline__ void softmax_pv32(const _Float16* __restrict__ kp, co
                     O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
                     if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
                 }
+#endif
         }
     } else {
         float m = 0.0f;
@@ -571,6 +636,9 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
     auto v_of = [&](const int t, const int st) { return *reinterpret_cast<const h8*>(vp + 16 * (2 * t + st)); };
     O = zero16;
     h8 qb2m = qb2;
+#if S2S_MFMA_SPLIT
+    const SelA sel = split_selectors(h);
+#endif
     float m = 0.0f;                                                       // the shift qb2m carries: exactly -(hi + lo)
 #pragma unroll
     for (int h2 = 0; h2 < NT / 2; ++h2) {
@@ -612,6 +680,16 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
 #else
         const float nm = -(h2 == 0 ? mh : m + fmaxf(mh, 0.0f));
 #endif
+#if S2S_INT_SHIFT
+        // (the shift need not be the maximum, only no smaller: rounded up to an integer it fits ONE f16 half -- exactly below 2048,
+        //  and what the half encodes is what is used otherwise -- so the lo half, its subtraction and two conversions go)
+        const _Float16 nh = (_Float16)(-__builtin_ceilf(-nm));
+        const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, (_Float16)0.0f}));
+        uv4 q2 = __builtin_bit_cast(uv4, qb2);
+        q2[0] = h ? pk : q2[0];
+        qb2m = __builtin_bit_cast(h8, q2);
+        const float m_enc = -(float)nh;
+#else
         const _Float16 nh = (_Float16)nm;
         const _Float16 nl = (_Float16)(nm - (float)nh);
         const unsigned pk = __builtin_bit_cast(unsigned, (h2v{nh, nl}));
@@ -619,6 +697,7 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
         q2[0] = h ? pk : q2[0];
         qb2m = __builtin_bit_cast(h8, q2);
         const float m_enc = -((float)nh + (float)nl);                     // what the two halves encode: exact in fp32
+#endif
         if (h2 > 0) {
             const float f = __builtin_amdgcn_exp2f(m - m_enc);            // (1 for a row whose maximum did not rise)
 #pragma unroll
@@ -632,6 +711,10 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
 #else
         score_pass();
 #endif
+#if S2S_MFMA_SPLIT
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pv_split_mfma<LO>(sc[i], va[i], sel, O);
+#else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -642,6 +725,7 @@ __device__ __forceinline__ void softmax_pv32_online(const _Float16* __restrict__
                 O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{h0, h1, h2_, h3})), O);
                 if (LO) O = MFMAW(va[i][st], __builtin_bit_cast(h8, (uv4{l0, l1, l2, l3})), O);
             }
+#endif
     }
 }
 // the constant rows behind the V region (see AttnLdsH): called once per kernel, before the first barrier

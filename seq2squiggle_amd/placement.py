@@ -261,7 +261,7 @@ def pin_rank(local_rank: Optional[int] = None, local_world: Optional[int] = None
         p = phys[local_rank]
         g = gpus[p] if p is not None and p < len(gpus) else {}
         from_sysfs = bool(g.get("cpus")) and set(mine) <= set(g["cpus"])
-        info = {"cpus": format_cpulist(mine), "n_cpus": len(mine), "numa_node": g.get("numa_node") if from_sysfs else None,
+        info = {"cpus": format_cpulist(mine), "n_cpus": len(mine), "allowed": format_cpulist(allowed), "numa_node": g.get("numa_node") if from_sysfs else None,
                 "bdf": g.get("bdf"), "source": "sysfs" if from_sysfs else "equal split"}
         if apply:
             os.sched_setaffinity(0, mine)

@@ -246,6 +246,41 @@ def test_rna_profile_streaming_equals_reference_flow(tmp_path):
     assert len(a[2]["signal"]) > 0.9 * 250 * -(-(700 - 8) // 16)
 
 
+def test_a_narrowed_rank_uses_its_one_device_and_ranks_never_share_one(tmp_path):
+    """a child of `predict --gpus N` sees exactly one device (HIP_VISIBLE_DEVICES = its own) and therefore uses
+    index 0 whatever its LOCAL_RANK; on a box with fewer GPUs than ranks the command FAILS (the rank whose device does not exist says
+    so, the launcher ends the others and returns non-zero) instead of quietly putting two ranks on one device."""
+    lam = os.path.join(GOLDEN, "example_lambda_genome.fasta")
+    base = [sys.executable, "-m", "seq2squiggle_amd", "predict", lam, "-n", "24", "-r", "2000", "-m",
+            os.path.join(GOLDEN, "synthetic_k9.ckpt"), "--seed", "5", "-v", "debug"]
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "S2S_ONE_GPU")}
+    first = (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or "0").split(",")[0]
+    # rank 3 of 4 as the launcher would start it on a node where its GPU is this box's one: narrowed to that device
+    env = dict(env0, RANK="3", LOCAL_RANK="3", WORLD_SIZE="4", LOCAL_WORLD_SIZE="4", HIP_VISIBLE_DEVICES=first, CUDA_VISIBLE_DEVICES=first,
+               S2S_PARENT_VISIBLE="")
+    r = subprocess.run(base + ["-o", str(tmp_path / "n.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "bound to CPUs" in r.stderr                                # placement.pin_rank ran before the first allocation (debug log)
+    _, narrowed = signal_io.read_blow5(str(tmp_path / "n.rank3.blow5"))
+    # ... the same shard from the rehearsal switch (every rank on cuda:0, nothing narrowed)
+    env = dict(env0, RANK="3", LOCAL_RANK="3", WORLD_SIZE="4", LOCAL_WORLD_SIZE="4", S2S_ONE_GPU="1", S2S_NO_PIN="1")
+    r = subprocess.run(base + ["-o", str(tmp_path / "o.blow5")], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "bound to CPUs" not in r.stderr                            # S2S_NO_PIN opts out
+    _, plain = signal_io.read_blow5(str(tmp_path / "o.rank3.blow5"))
+    assert len(narrowed) == len(plain) > 0
+    for a, b in zip(narrowed, plain):
+        assert a["read_id"] == b["read_id"] and np.array_equal(a["signal"], b["signal"])
+    # two ranks, one GPU, no rehearsal switch: rank 1's device does not exist -> the command fails, no output file, no rank left behind
+    if len((os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")) == 1:
+        if torch.cuda.device_count() == 1:
+            r = subprocess.run(base + ["-o", str(tmp_path / "two.blow5"), "--gpus", "2"], cwd=ROOT, capture_output=True, text=True,
+                               timeout=600, env=dict(env0, S2S_RANK_GRACE="5"))
+            assert r.returncode != 0, r.stdout[-1000:]
+            assert not os.path.exists(tmp_path / "two.blow5")
+            assert "rank 1 exited" in r.stderr or "rank 1" in r.stderr
+
+
 def test_three_rank_shards_equal_the_single_gpu_run(tmp_path):
     """SURVEY 8e on the real device path: RANK/WORLD_SIZE = r/3 runs (one after the other, all on GPU 0) write
     out.rank{r}.blow5; their reads, concatenated in rank order, carry exactly the samples of the single-process run
