@@ -567,7 +567,8 @@ def one_command(mode, world, n_total, fasta, td, join="after"):
         return {"skipped": "one-GPU rehearsal: ranks of the bench + ranks of the command would exceed the pool's process limit"}
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
-                        "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS") and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_"))}
+                        "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS", "S2S_PINNED_CPUS", "S2S_PARENT_VISIBLE")
+           and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_"))}
     env["S2S_TIMING_JSON"] = os.path.join(td, "timing.json")
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     if os.environ.get("S2S_BENCH_ONE_GPU"):
@@ -577,7 +578,8 @@ def one_command(mode, world, n_total, fasta, td, join="after"):
            os.path.join(ROOT, "tests", "golden", "synthetic_k9.ckpt"), "--compute-mode", mode, "-v", "warning"] + (["--join", join] if join != "after" else [])
     t0 = time.perf_counter()
     # its own process group: on a timeout the command AND the ranks it started are ended (by that group id), nothing is orphaned on a GPU
-    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    with unpinned():                                              # (the command places its own ranks: it starts from this rank's ORIGINAL mask)
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
         stdout, stderr = proc.communicate(timeout=110)            # (both joins fit the leg's 300-s barrier)
     except subprocess.TimeoutExpired:
@@ -599,6 +601,33 @@ def one_command(mode, world, n_total, fasta, td, join="after"):
     except (OSError, ValueError):
         pass
     return out
+
+
+_PIN = None               # placement.pin_rank's record for this rank (None: not pinned)
+
+
+class unpinned:
+    """A child process inherits the affinity mask of the thread that starts it: children of a PINNED bench rank (the RCCL self-test,
+    `predict --gpus N` with ranks and a placement of its own) must start from the mask this rank had before it bound itself."""
+
+    def __enter__(self):
+        self.back = None
+        if _PIN and _PIN.get("allowed") and hasattr(os, "sched_setaffinity"):
+            try:
+                from seq2squiggle_amd.placement import parse_cpulist
+                self.back = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, parse_cpulist(_PIN["allowed"]))
+            except (OSError, ValueError):
+                self.back = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.back is not None:
+            try:
+                os.sched_setaffinity(0, self.back)
+            except OSError:
+                pass
+        return False
 
 
 class HostGroup:
@@ -720,8 +749,9 @@ def rccl_selftest(n_ranks, limit_s=120.0):
             if one_gpu:
                 env["S2S_ONE_GPU"] = "1"
             # (all devices stay visible to a child: RCCL's peer-to-peer transport wants to see its neighbours; the child picks LOCAL_RANK)
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rccl-selftest-child"], env=env, cwd=ROOT,
-                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True))
+            with unpinned():
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rccl-selftest-child"], env=env, cwd=ROOT,
+                                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True))
         deadline = time.perf_counter() + limit_s
         outs = []
         for p in procs:
@@ -769,10 +799,27 @@ def launch_ranks(a, argv):
     if a.dry_launch:
         print(json.dumps({"dry_launch": cmd}))
         return 0
+    import signal
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in p.stdout.splitlines():
+    # the launcher and its ranks in a session of their own: SIGTERM / SIGHUP / Ctrl-C to this parent ends all of them (by process
+    # group), nothing stays behind on a GPU
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+    def end(signum, frame):
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        sys.exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+        signal.signal(sig, end)
+    out, _ = p.communicate()
+    for line in out.splitlines():
         if line.startswith("{"):
             print(line)
         elif line.strip():
@@ -866,7 +913,8 @@ def main():
     if one_gpu:
         os.environ["S2S_ONE_GPU"] = "1"                         # (placement.local_device, inference_run)
     from seq2squiggle_amd import placement
-    pinned = placement.pin_rank() if world > 1 else None        # before the first GPU call and the first pinned page
+    global _PIN
+    pinned = _PIN = placement.pin_rank() if world > 1 else None  # before the first GPU call and the first pinned page
     local = placement.local_device()
     host = HostGroup(world)                                      # gloo on host tensors: the bench needs no RCCL (the path has no exchange)
     selftest_mode = a.launch_selftest

@@ -105,6 +105,30 @@ def test_line_is_written_once(tmp_path, capfd):
     os.close(r)
 
 
+def test_children_of_a_pinned_rank_start_from_its_original_mask(monkeypatch):
+    """A child inherits the affinity of the thread that starts it: the RCCL self-test's children and the `predict --gpus N` leg (which
+    places its own ranks) must not be squeezed into rank 0's share of the node."""
+    if not hasattr(os, "sched_setaffinity") or len(os.sched_getaffinity(0)) < 2:
+        import pytest
+        pytest.skip("needs two allowed CPUs")
+    sys.path.insert(0, ROOT)
+    import bench
+    from seq2squiggle_amd.placement import format_cpulist
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        os.sched_setaffinity(0, before[:1])                          # "pinned" to one CPU
+        monkeypatch.setattr(bench, "_PIN", {"allowed": format_cpulist(before)})
+        with bench.unpinned():
+            child = subprocess.run([sys.executable, "-c", "import os; print(sorted(os.sched_getaffinity(0)))"], capture_output=True, text=True).stdout
+        assert eval(child) == before
+        assert sorted(os.sched_getaffinity(0)) == before[:1]         # ... and this rank is bound again afterwards
+        monkeypatch.setattr(bench, "_PIN", None)
+        with bench.unpinned():
+            assert sorted(os.sched_getaffinity(0)) == before[:1]     # not pinned by the bench: nothing to undo
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_devices_distinct():
     sys.path.insert(0, ROOT)
     import bench

@@ -387,8 +387,7 @@ def test_rank_shards_in_read_mode_skip_dropped_reads(tmp_path):
 
 def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
     """`bench.py --gpus 2` exactly as the driver starts it (children of an untouched parent, torchrun rendezvous on
-    127.0.0.1), rehearsed on this box's ONE GPU (S2S_BENCH_ONE_GPU: both ranks on cuda:0, gloo barrier -- RCCL refuses two
-    ranks per device).  It cannot measure scaling (the ranks share the GPU) but it runs everything the 8-GPU line will run:
+    127.0.0.1), rehearsed on this box's ONE GPU (S2S_BENCH_ONE_GPU: both ranks on cuda:0; the barrier is a host group at any N).  It cannot measure scaling (the ranks share the GPU) but it runs everything the 8-GPU line will run:
     the N > 1 code path of the timed loop, the sharded end-to-end leg (each rank: FASTA parse, native sampler skip-ahead,
     its read shard, cpu_share() = quota / LOCAL_WORLD_SIZE threads, its own shard file) and the max-over-ranks timing.
     Checked: one JSON line, both ranks seen, the shards add up to the whole job, and two ranks sharing one GPU move at
@@ -402,7 +401,17 @@ def test_two_ranks_on_one_gpu_bench_rehearsal(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and len(d["per_rank_chunks_per_sec"]) == 2
-    assert "end_to_end" not in d and "cpu_baseline" not in d
+    # the N > 1 line (round 6): the ranks met on a HOST group, every rank says what it ran on, RCCL is a reported self-test (two ranks
+    # on ONE device: RCCL refuses -- reported, nothing else lost), and the CPU baseline with its live parity check is there as at N = 1
+    assert "end_to_end" not in d and d["barrier_backend"] == "gloo"
+    dev = d["per_rank_device"]
+    assert len(dev) == 2 and dev[0]["pci"] == dev[1]["pci"] and dev[0]["pid"] != dev[1]["pid"]
+    assert d["devices_distinct"] is False and "one_gpu_rehearsal" in d and "invalid" not in d
+    assert dev[0]["cpus"] and dev[1]["cpus"] and dev[0]["cpus"] != dev[1]["cpus"]          # each rank on its own share of the GPU's socket
+    assert d["rccl_selftest"]["n_ranks"] == 2 and d["rccl_selftest"]["ok"] in (True, False)
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["parity"]["signal_mae_pa"] < 1e-4 and cb["parity"]["dwell_indices_equal"] and cb["parity"]["zero_pattern_equal"]
+    assert "secondary_legs_timed_out" not in d
     e = d["end_to_end_sharded"]
     # lambda genome -n 25000 -r 5000, seed 42: the read set of the single-process run, split in two contiguous shards
     assert len(e["per_rank_chunks"]) == 2 and abs(e["per_rank_chunks"][0] - e["per_rank_chunks"][1]) < 0.02 * e["chunks"]

@@ -9,11 +9,11 @@ T=$1
 mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp
 for m in f16x3 f32; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats_$m -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode $m > $R/gpurun_out/$T/bench_${m}_under_rocprof.json 2> $R/gpurun_out/$T/stats_$m.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats_$m -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode $m > $R/gpurun_out/$T/bench_${m}_under_rocprof.json 2> $R/gpurun_out/$T/stats_$m.err
   bash $R/tools/pmc_run.sh $T/pmc_$m --mode $m
 done
 # the exact attention instance (s2s_fused_kernel<1, false, true>) forced on the same workload: kernel stats only
-S2S_ATTENTION_PATH=exact rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats_f16x3_exact -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode f16x3 > $R/gpurun_out/$T/bench_f16x3_exact_under_rocprof.json 2> $R/gpurun_out/$T/stats_f16x3_exact.err
+S2S_ATTENTION_PATH=exact timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/stats_f16x3_exact -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode f16x3 > $R/gpurun_out/$T/bench_f16x3_exact_under_rocprof.json 2> $R/gpurun_out/$T/stats_f16x3_exact.err
 S2S_ATTENTION_PATH=exact bash $R/tools/pmc_run.sh $T/pmc_f16x3_exact --mode f16x3
 cd $R && python3 bench.py > gpurun_out/$T/bench_f16x3.json 2> gpurun_out/$T/bench_f16x3.err
 python3 tools/pmc_summarize.py f32=gpurun_out/$T/pmc_f32:65520 f16x3=gpurun_out/$T/pmc_f16x3:65520 f16x3_exact=gpurun_out/$T/pmc_f16x3_exact:65520 > gpurun_out/$T/pmc_summary.json
