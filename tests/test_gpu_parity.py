@@ -190,6 +190,31 @@ def test_predict_modes_vs_reference_goldens(case, key, over, use_g, use_z, use_z
         assert (out["dur"].cpu().numpy() == 12).all()
 
 
+def test_wide_reference_goldens(case):
+    """Round 6: ~220 chunks per chemistry of real (lambda) sequence, homopolymers, a repeat, an N-rich read and short tails, through
+    the IMPORTED reference's predict_step with injected variates (tests/golden/wide_*.npz, tools/make_goldens.py wide): the HIP path
+    against the reference itself on four times the chunks of the stage goldens, in both arithmetic modes and on both attention
+    paths.  The bound is the file's: dwell indices and zero pattern exact, MAE < 1e-4 pA, max < 2e-3 pA."""
+    eng, dev = case["eng"], case["dev"]
+    g = load_npz(f"wide_{case['tag']}.npz")
+    bases, nv = chunker.codes_to_bases(g["codes"])
+    b, n = torch.from_numpy(bases).to(dev), torch.from_numpy(nv).to(dev)
+    z = torch.from_numpy(g["z01"].astype(np.float32)).to(dev)
+    out = eng.predict_chunks(b, n, S.PredictParams(**P()), inject_g=torch.from_numpy(g["g"]).to(dev), inject_z01=z)
+    assert np.array_equal(out["dur"].cpu().numpy(), g["dur_gamma"])
+    y, ref = out["signal"].cpu().numpy(), g["y_gamma_nsamp"]
+    assert np.array_equal(y == 0, ref == 0)
+    d = np.abs(y - ref)
+    assert d.mean() < MAE_TOL and d.max() < MAX_TOL, (d.mean(), d.max())
+    out = eng.predict_chunks(b, n, S.PredictParams(**P(noise_std=1.0, noise_sampling=False, duration_sampling=False)), inject_z01=z)
+    y2, ref2 = out["signal"].cpu().numpy(), g["y_ideal_nconst"]
+    assert (out["dur"].cpu().numpy() == 12).all() and np.array_equal(y2 == 0, ref2 == 0)
+    d2 = np.abs(y2 - ref2)
+    assert d2.mean() < MAE_TOL and d2.max() < MAX_TOL, (d2.mean(), d2.max())
+    print(f"WIDE {case['tag']} {eng.mode} {eng.attention_path}: {y.shape[0]} chunks, gamma + sampled noise MAE {d.mean():.2e} max {d.max():.2e}; "
+          f"ideal + constant noise MAE {d2.mean():.2e} max {d2.max():.2e}")
+
+
 def test_random_batch_vs_oracle(case):
     """Seeded random chunks (with N and short tails) at a size the oracle does in seconds."""
     k, eng, dev = case["cfg"]["seq_kmer"], case["eng"], case["dev"]

@@ -90,6 +90,32 @@ def test_predict_step_modes(model_case, key, over, use_g, use_z, use_zdw):
     assert np.abs(y - ref).mean() < 1e-4 and np.abs(y - ref).max() < 2e-3      # pA
 
 
+@pytest.mark.parametrize("tag", ["k9", "k6"])
+def test_wide_goldens(tag):
+    """Round 6: ~220 chunks per chemistry of real (lambda) sequence and edge reads through the IMPORTED reference's predict_step
+    (tools/make_goldens.py wide) -- four times the stage goldens' chunk count, and real sequence pinned by the reference itself
+    rather than through this oracle alone."""
+    sd, cfg = load_ckpt(tag)
+    g = load_npz(f"wide_{tag}.npz")
+    B = g["codes"].shape[0]
+    assert B > 200 and len(set(g["names"].tolist())) == 12
+    z = torch.from_numpy(g["z01"].astype(np.float32))
+    out = O.predict_chunks(sd, cfg, g["codes"], P(), inject_g=torch.from_numpy(g["g"]), inject_z01=z)
+    assert np.array_equal(out["dur"].numpy(), g["dur_gamma"])                   # dwell indices: bit-exact
+    y, ref = out["signal"].numpy(), g["y_gamma_nsamp"]
+    assert np.array_equal(y == 0, ref == 0)
+    assert np.abs(y - ref).mean() < 1e-4 and np.abs(y - ref).max() < 2e-3      # pA
+    out = O.predict_chunks(sd, cfg, g["codes"], P(noise_std=1.0, noise_sampling=False, duration_sampling=False), inject_z01=z)
+    y, ref = out["signal"].numpy(), g["y_ideal_nconst"]
+    assert (out["dur"].numpy() == 12).all()
+    assert np.array_equal(y == 0, ref == 0)
+    assert np.abs(y - ref).mean() < 1e-4 and np.abs(y - ref).max() < 2e-3
+    # the duration sampler's output for the injected standard-gamma draws is what the reference computed: sg / rate
+    _, emb_out = O.encoder(sd, cfg, O.one_hot(g["codes"]).reshape(B, 16, -1))
+    _, rate = O.duration_params(sd, emb_out)
+    assert np.allclose(O.standard_gamma_to_sample(torch.from_numpy(g["sg"]), rate).numpy(), g["g"], rtol=2e-5, atol=1e-6)
+
+
 def test_fp64_truth_distance(model_case):
     """Report-style check: the fp32 reference sits ~1e-5 pA from an fp64 evaluation; so must the oracle."""
     tag, sd, cfg, g = model_case

@@ -9,7 +9,7 @@ modules / predict_step / export / BLOW5Writer.save with *injected* random
 variates.  Outputs (data only -- inputs and expected outputs) go to
 tests/golden/.  Nothing of the reference's source text is written.
 
-    python tools/make_goldens.py
+    python tools/make_goldens.py [pod5 | mixed16 | wide]
 """
 import os
 import sys
@@ -531,8 +531,68 @@ def mixed16_goldens():
     np.savez_compressed(os.path.join(OUT, "mixed16.npz"), **out)
 
 
+def wide_goldens():
+    """More chunks through the reference itself (round 6: the stage goldens hold 51 / 56 chunks per chemistry; everything wider was
+    checked through the oracle only).  The committed checkpoints, ~256 chunks per chemistry of REAL sequence -- windows of the
+    reference's lambda genome example -- plus the edge reads of the test suites (homopolymers, a dinucleotide repeat, an N-rich read,
+    reads that end in a short tail), the reference's predict_step with injected variates in two configurations (the default
+    samplers: Gamma dwell + sampled noise; ideal dwell + constant noise), and the dwell indices of the Gamma run.
+    -> tests/golden/wide_{k9,k6}.npz: codes, sg (injected standard-gamma draws), g (the duration sampler's output for them), z01
+    (injected normals), y_gamma_nsamp, dur_gamma, y_ideal_nconst.  The normals are stored as float16-exact values (drawn, then rounded to float16 and used as such) to halve
+    the fixture; they are injected variates, any values do."""
+    lam = read_fasta(os.path.join(REF, "example", "lamda_genome.fasta"))[0][0].upper()        # (the reference's own spelling)
+    for tag, seed in (("k9", 31), ("k6", 32)):
+        ck = torch.load(os.path.join(OUT, f"synthetic_{tag}.ckpt"), map_location="cpu", weights_only=True)
+        cfg = ck["hyper_parameters"]["config"]
+        m = RM.seq2squiggle(config=cfg)
+        m.load_state_dict(ck["state_dict"])
+        m.eval()
+        rng = np.random.default_rng(seed)
+        reads = []
+        for i, start in enumerate(rng.integers(0, len(lam) - 700, size=6)):
+            L = int(rng.integers(380, 640))
+            reads.append((lam[int(start):int(start) + L], f"lambda_{i}"))
+        reads += [("A" * 90, "homopolymer_A"), ("T" * 57, "homopolymer_T"), ("ACACACACAC" * 11, "dinucleotide"),
+                  ("".join(rng.choice(list("ACGTN"), 130, p=[.2, .2, .2, .2, .2])), "n_rich"),
+                  (lam[1000:1000 + 16 * 3 + cfg["seq_kmer"]], "ends_on_a_chunk_boundary"),
+                  (lam[5000:5000 + 16 * 2 + cfg["seq_kmer"] + 5], "short_tail")]
+        names, chunks = [], []
+        for seq, name in reads:
+            for c in RU.split_sequence(seq, cfg):
+                names.append(name)
+                chunks.append(c)
+        x = np.stack(chunks)
+        B = x.shape[0]
+        x16 = torch.from_numpy(x)
+        gen = torch.Generator().manual_seed(1000 + seed)
+        enc_out, emb_out = m.encoders(x16.reshape(B, 16, -1))
+        sigma = m.noise_sampler(emb_out)
+        ds = m.length_regulator.duration_sampler
+        conc = torch.clamp(ds.conc_layer(emb_out), min=1e-8)
+        sg = torch._standard_gamma(conc, generator=gen)
+        z250 = torch.randn(B, 250, generator=gen).half().float()
+        common = dict(dwell_mean=12.5, dwell_std=0.0, min_duration=3)
+        with Inject(sg=sg, z_normal=[z250]):
+            y = run_predict_step(m, names, x16, noise_std=2.0, noise_sampling=True, duration_sampling=True, min_noise=0.0, **common)
+        with Inject(sg=sg):
+            _, dpo, _, _, _ = m.length_regulator(emb_out=emb_out, x=enc_out, target=None, noise_std_prediction=sigma[:, :, None],
+                                                 max_length=250, dwell_mean=12.5, dwell_std=0.0, duration_sampling=True, min_length=3)
+        with Inject(z_normal=[z250]):
+            yi = run_predict_step(m, names, x16, noise_std=1.0, noise_sampling=False, duration_sampling=False, min_noise=0.0, **common)
+        with Inject(sg=sg):
+            g_samp, _ = ds(emb_out)                          # the duration sampler's output for these draws: what the engine takes as inject_g
+        out = {"codes": codes_from_onehot(x), "names": np.array(names), "sg": sg.flatten(1).numpy(), "g": g_samp.numpy(), "z01": z250.half().numpy(),
+               "y_gamma_nsamp": y.numpy(), "dur_gamma": torch.round(dpo).int().numpy(), "y_ideal_nconst": yi.numpy()}
+        np.savez_compressed(os.path.join(OUT, f"wide_{tag}.npz"), **out)
+        print(tag, "wide:", B, "chunks from", len(reads), "reads; zeros in y:", int((out["y_gamma_nsamp"] == 0).sum()),
+              "bytes", os.path.getsize(os.path.join(OUT, f"wide_{tag}.npz")))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["wide"]:          # only the wide goldens (they read the committed checkpoints)
+        wide_goldens()
+        return
     if sys.argv[1:] == ["pod5"]:          # only the POD5 record goldens (they read the committed signals_*.npz)
         pod5_goldens()
         return
@@ -554,6 +614,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "position_enc.npz"), **pe)
     pod5_goldens()
     mixed16_goldens()
+    wide_goldens()
     print("goldens written to", OUT)
 
 
