@@ -8,7 +8,7 @@ min_duration 3), synthetic k=9 checkpoint.  With N>1 every rank runs the same am
 its own read shard (weak scaling, no data-path collective).  The path has no exchange step, so the bench needs no RCCL:
 the barrier around the timed region, the max-over-ranks and the per-rank gather run on a HOST (gloo) group, each side of a
 torch.cuda.synchronize().  RCCL is a reported self-test (`rccl_selftest`: N throw-away child processes, wall-limited, started
-after the timed region so that nothing it does can cost the measurement), not a dependency.
+as the last leg that touches a GPU so that nothing it does can cost a measurement), not a dependency.
 
 `python bench.py --gpus N` without a torchrun environment starts its N ranks itself, as CHILD processes
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`), before
@@ -1102,14 +1102,6 @@ def main():
         if rank == 0:
             line.write()
         os._exit(0)
-    if world > 1:
-        # RCCL, reported: after the measurement, in processes of their own (rank 0 starts them, the others wait at the host barrier)
-        try:
-            res = rccl_leg()
-        except Exception as e:
-            res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
-        if rank == 0:
-            out["rccl_selftest"] = res
     if rank == 0 and not a.no_cpu_baseline:
         if world == 1:
             leg("end_to_end", end_to_end, a.mode)
@@ -1124,14 +1116,31 @@ def main():
                 leg("weight_sensitivity", weight_sensitivity_leg, a.mode, bases_d, nv_d, sig, dur, params, max(2, min(a.steps, 5)))
             if a.mode == "f16x3":
                 leg("reduced_precision", reduced_precision_leg, sd, cfg, bases_d, nv_d, sig, dur, params, a.steps)
+    selftest_clean = 1.0
     try:
-        host.barrier()
+        host.barrier()                                         # (N > 1: the others waited here while rank 0 ran its legs)
+        if world > 1:
+            # RCCL, reported: the LAST thing that touches the GPUs, in processes of their own (rank 0 starts them, the others wait at the
+            # host barrier inside rccl_leg): whatever it does to a device, every other field of the line has been measured by now
+            try:
+                res = rccl_leg()
+            except Exception as e:
+                res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                out["rccl_selftest"] = res
+                selftest_clean = 0.0 if (res and res.get("ok") is False and "killed" in str(res.get("error", ""))) else 1.0
+            selftest_clean = -host.max(-selftest_clean)         # (min over ranks: rank 0's verdict reaches everybody)
     except Exception as e:                                     # (rank 0 took longer than the group's timeout: the others just leave)
         print(f"bench.py: rank {rank}: final barrier: {type(e).__name__}: {e}", file=sys.stderr)
         if rank != 0:
             os._exit(0)
     if rank == 0:
         line.write()
+    if selftest_clean < 1.0:
+        # self-test children had to be killed: a device may be wedged under them -- leave without a teardown that could wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3 if (rank == 0 and out.get("invalid")) else 0)
     eng.close()
     host.close()
     if rank == 0 and out.get("invalid"):
