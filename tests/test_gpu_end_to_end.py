@@ -214,6 +214,12 @@ def test_bench_contract_line():
     assert rf["peak"] == 2500.0                       # the guide's dense f16 peak, not a derated one
     assert abs(rf["frac_of_f16x3_ceiling"] - 3 * rf["frac"]) < 1e-9 and rf["x_of_f32_mfma_peak"] > 0
     assert d["n_ranks_seen"] == 1 and len(d["per_rank_chunks_per_sec"]) == 1
+    # round 6: the profiled constants in the line say which sources they were measured on -- the committed summary must be that of
+    # THIS tree's kernel sources (re-run tools/pmc_run.sh + pmc_summarize.py after touching csrc/) -- and how much of the matrix work is padding
+    assert rf["pmc_stale"] is False, (rf["pmc_csrc_sha256"], rf["csrc_sha256"], rf["traffic_source"])
+    assert 0.15 < rf["mfma_useful_frac"] < 1 / 3 and abs(rf["mfma_useful_frac"] * rf["mfma_issued_flop_per_chunk"] - rf["flop_per_chunk"]) < 1
+    assert rf["traffic"] > rf["algorithmic_bytes_per_launch"] > 0
+    assert d["barrier_backend"] is None and d["devices_distinct"] is True and len(d["per_rank_device"]) == 1 and d["per_rank_device"][0]["pci"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["parity"]["dwell_indices_equal"] and cb["parity"]["signal_mae_pa"] < cb["parity"]["tolerance_mae_pa"]
