@@ -67,6 +67,24 @@ def test_a_selftest_child_that_never_answers_is_killed_and_reported():
     assert not [l for l in out.splitlines() if "--rccl-selftest-child" in l]
 
 
+def test_eight_ranks_meet_and_report(tmp_path):
+    """The driver's largest N through the same plumbing (no GPU): eight ranks on the host group, eight identities, eight disjoint
+    CPU sets (when this box has eight CPUs to give), the self-test reported, one line."""
+    p = _run("--gpus", "8", "--launch-selftest", "--rccl-selftest-limit", "60", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_ranks_seen"] == 8 and d["sum_of_ones"] == 8 and d["barrier_backend"] == "gloo"
+    dev = d["per_rank_device"]
+    assert [r["rank"] for r in dev] == list(range(8)) and len({r["pid"] for r in dev}) == 8
+    if all(r["cpus"] for r in dev) and len(os.sched_getaffinity(0)) >= 8:
+        from seq2squiggle_amd.placement import parse_cpulist
+        sets = [set(parse_cpulist(r["cpus"])) for r in dev]
+        assert sum(len(x) for x in sets) == len(set().union(*sets))              # pairwise disjoint
+    assert d["rccl_selftest"]["n_ranks"] == 8 and "ok" in d["rccl_selftest"]
+
+
 def test_selftest_limit_zero_skips_it():
     p = _run("--gpus", "2", "--launch-selftest", "--rccl-selftest-limit", "0", "--no-cpu-baseline")
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
