@@ -287,6 +287,60 @@ def reduced_precision_leg(sd, cfg, bases_d, nv_d, sig, dur, params, steps):
     return out
 
 
+def parse_rocm_smi(text):
+    """`rocm-smi --showpower --showclocks --showmaxpower` (text form) -> {"watts", "cap_watts", "sclk_mhz"} of GPU[0] (None where absent)."""
+    import re
+
+    def first(pat):
+        m = re.search(pat, text)
+        return float(m.group(1)) if m else None
+    return {"watts": first(r"GPU\[0\]\s*:\s*Current Socket Graphics Package Power \(W\):\s*([0-9.]+)") or
+            first(r"GPU\[0\]\s*:\s*Average Graphics Package Power \(W\):\s*([0-9.]+)"),
+            "cap_watts": first(r"GPU\[0\]\s*:\s*Max Graphics Package Power \(W\):\s*([0-9.]+)"),
+            "sclk_mhz": first(r"GPU\[0\]\s*:\s*sclk clock level:[^(]*\(([0-9.]+)Mhz\)")}
+
+
+def power_leg(eng, bases_d, nv_d, sig, dur, params, seconds=7.0):
+    """What bounds this kernel, LIVE: the package power and shader clock `rocm-smi` reports while the headline's launches run back to
+    back on a helper thread (three samples, the first after 2.5 s), and the energy per chunk that follows.  The f16x3 kernel sits at
+    the package's power cap: its speed is energy per chunk, not issue slots (profiles/r06/ab_mfma_split.txt)."""
+    import threading
+    stop, done = threading.Event(), {"launches": 0}
+
+    def run():
+        torch.cuda.set_device(eng.device)
+        while not stop.is_set():
+            eng.predict_chunks(bases_d, nv_d, params, out_signal=sig, out_dur=dur)
+            done["launches"] += 1
+            if done["launches"] % 4 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = threading.Thread(target=run, name="s2s-power-load")
+    th.start()
+    samples = []
+    try:
+        time.sleep(2.5)
+        while time.perf_counter() - t0 < seconds and len(samples) < 3:
+            r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=20)
+            samples.append(parse_rocm_smi(r.stdout))
+            time.sleep(0.7)
+    finally:
+        stop.set()
+        th.join()
+    el = time.perf_counter() - t0
+    rate = done["launches"] * bases_d.shape[0] / el
+    watts = [x["watts"] for x in samples if x.get("watts")]
+    if not watts:
+        return {"error": "rocm-smi reported no package power", "chunks_per_sec": rate}
+    w = sum(watts) / len(watts)
+    cap = next((x["cap_watts"] for x in samples if x.get("cap_watts")), None)
+    return {"package_watts": w, "package_watts_samples": watts, "cap_watts": cap, "of_cap": (w / cap) if cap else None,
+            "sclk_mhz_samples": [x["sclk_mhz"] for x in samples], "chunks_per_sec": rate, "microjoule_per_chunk": w / rate * 1e6,
+            "source": "rocm-smi --showpower --showclocks --showmaxpower, sampled while the headline's launches run back to back"}
+
+
 FLOP_PER_CHUNK_K6 = 85_052_672         # k = 6: the embedding gather takes 6 columns instead of 9, everything else is the same
 
 
@@ -1111,6 +1165,7 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["gpu_over_cpu_note"] = "whole job over ONE host's CPU baseline" if world > 1 else None
         if world == 1:
+            leg("power", power_leg, eng, bases_d, nv_d, sig, dur, params)
             leg("config4_k6", config4_k6_leg, a.mode, dev, a.steps)
             if a.mode != "f32":
                 leg("weight_sensitivity", weight_sensitivity_leg, a.mode, bases_d, nv_d, sig, dur, params, max(2, min(a.steps, 5)))

@@ -147,6 +147,17 @@ def test_children_of_a_pinned_rank_start_from_its_original_mask(monkeypatch):
         os.sched_setaffinity(0, before)
 
 
+def test_rocm_smi_text_is_parsed():
+    sys.path.insert(0, ROOT)
+    import bench
+    text = ("GPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: 1: (2263Mhz)\n"
+            "======================================= Power Cap ========================================\n"
+            "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n"
+            "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1348.0\n")
+    assert bench.parse_rocm_smi(text) == {"watts": 1348.0, "cap_watts": 1400.0, "sclk_mhz": 2263.0}
+    assert bench.parse_rocm_smi("nothing here") == {"watts": None, "cap_watts": None, "sclk_mhz": None}
+
+
 def test_devices_distinct():
     sys.path.insert(0, ROOT)
     import bench

@@ -220,6 +220,8 @@ def test_bench_contract_line():
     assert 0.15 < rf["mfma_useful_frac"] < 1 / 3 and abs(rf["mfma_useful_frac"] * rf["mfma_issued_flop_per_chunk"] - rf["flop_per_chunk"]) < 1
     assert rf["traffic"] > rf["algorithmic_bytes_per_launch"] > 0
     assert d["barrier_backend"] is None and d["devices_distinct"] is True and len(d["per_rank_device"]) == 1 and d["per_rank_device"][0]["pci"]
+    pw = d["power"]                                   # live: what the package drew while the launches ran (here: small launches, not the cap)
+    assert "error" in pw or (pw["package_watts"] > 100 and pw["cap_watts"] >= pw["package_watts"] * 0.5 and pw["microjoule_per_chunk"] > 0)
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["parity"]["dwell_indices_equal"] and cb["parity"]["signal_mae_pa"] < cb["parity"]["tolerance_mae_pa"]
